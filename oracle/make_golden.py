@@ -1,0 +1,225 @@
+"""ORACLE fixture generator (test infrastructure; runs ONLY in the build container).
+
+Imports the reference's own PyTorch modules from /root/reference (read-only, no
+bytecode written), fills them with the deterministic weights of
+oracle/detweights.py, runs them on deterministic inputs on the CPU and stores
+small .npz fixtures (inputs are regenerated from seeds; outputs are strided
+samples + summary statistics) under tests/golden/.  The reference itself never
+travels: tests on the GPU box only read the .npz files.
+
+Stubs: `torchvision`, `efficientnet_pytorch`, `cv2` are imported by the reference
+but unused on this path; `spatial_correlation_sampler` is an absent third-party
+extension, replaced here by the oracle's restatement (oracle/ref_models.py,
+oracle/corr_ref.c) — fixtures that pass through it are labelled
+corr="assumed-semantics".
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+REF = os.environ.get("SDHIP_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from oracle import ref_models as R  # noqa: E402
+from oracle.detweights import fill_state_dict, rand_input, randn_input  # noqa: E402
+
+
+def _install_stubs():
+    for name in ("torchvision", "torchvision.models", "torchvision.transforms", "torchvision.datasets", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    for sub in ("models", "transforms", "datasets"):
+        setattr(sys.modules["torchvision"], sub, sys.modules["torchvision." + sub])
+    eff = types.ModuleType("efficientnet_pytorch")
+    eff.EfficientNet = type("EfficientNet", (), {})
+    sys.modules["efficientnet_pytorch"] = eff
+    scs = types.ModuleType("spatial_correlation_sampler")
+    scs.SpatialCorrelationSampler = R.SpatialCorrelationSampler
+    sys.modules["spatial_correlation_sampler"] = scs
+    torch.Tensor.cuda = lambda self, *a, **k: self  # PSMNet / HANet hard-code .cuda()
+    sys.path.insert(0, REF)
+
+
+def sample(t, stride=8):
+    """Strided sample + summary statistics of a tensor (what the fixtures store)."""
+    t = t.detach().float()
+    idx = tuple(slice(None, None, stride if (d >= t.dim() - 2 and t.shape[d] > 16) else
+                      (4 if (d == 1 and t.dim() == 4 and t.shape[1] >= 64) else 1)) for d in range(t.dim()))
+    return {"sample": t[idx].contiguous().numpy(), "mean": np.float64(t.double().mean()),
+            "absmean": np.float64(t.double().abs().mean()), "l2": np.float64(t.double().pow(2).sum().sqrt())}
+
+
+def flat(prefix, d):
+    return {"%s.%s" % (prefix, k): v for k, v in d.items()}
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def train_loss(outs, seg, disp):
+    """The loss of the timed step (torch_implementation.py:279,293,304,325) without Lovasz: CE(seg1)+CE(seg2)+L1(disp)."""
+    seg1, d1, seg2, _ = outs
+    ce = lambda y: torch.mean(torch.sum(-seg * F.log_softmax(y, 1), 1))  # util/utilTorchLoss.py:373-378
+    return ce(seg1) + ce(seg2) + F.l1_loss(d1, disp)
+
+
+def grad_norms(model, depth=1):
+    acc = {}
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        key = ".".join(k.split(".")[:depth])
+        acc[key] = acc.get(key, 0.0) + float(p.grad.double().pow(2).sum())
+    return {k: np.float64(np.sqrt(v)) for k, v in acc.items()}
+
+
+# --------------------------------------------------------------------------- per-op fixtures
+def gen_ops():
+    from models import torch_model as TM
+    from models import dsnet_t2 as D
+    arrays = {}
+    cases = [  # (name, cin, cout, k, stride, dil, H, W)
+        ("c1", 8, 16, 1, 1, 1, 9, 11), ("c3", 16, 8, 3, 1, 1, 12, 17), ("c5", 8, 8, 5, 1, 1, 13, 16),
+        ("c7s2", 3, 8, 7, 2, 1, 17, 20), ("c5d2", 3, 1, 5, 1, 2, 16, 19), ("c3s2", 8, 8, 3, 2, 1, 15, 16)]
+    for name, ci, co, k, s, d, H, W in cases:
+        ref = fill_state_dict(TM.conv2dSame(ci, co, k, s, 'same', d, bias=True), 11)
+        mine = R.conv2dSame(ci, co, k, s, 'same', d, bias=True)
+        mine.load_state_dict(ref.state_dict())
+        x = randn_input(11, name, (2, ci, H, W)).requires_grad_(True)
+        y = ref(x)
+        g = randn_input(12, name, tuple(y.shape))
+        y.backward(g)
+        arrays.update({"conv.%s.y" % name: y.detach().numpy(), "conv.%s.gx" % name: x.grad.numpy(),
+                       "conv.%s.gw" % name: ref.c2d.weight.grad.numpy(), "conv.%s.gb" % name: ref.c2d.bias.grad.numpy()})
+        assert torch.allclose(mine(x), y, atol=1e-6)
+    dcases = [("d3", 8, 16, 3, 1, 12, 17), ("d5", 8, 4, 5, 1, 13, 16), ("d3s2", 8, 8, 3, 2, 7, 9), ("d5s2", 4, 8, 5, 2, 6, 8)]
+    for name, ci, co, k, s, H, W in dcases:
+        ref = fill_state_dict(TM.ConvTranspose2dSame(ci, co, k, s, 'same', 1, bias=True), 13)
+        mine = R.ConvTranspose2dSame(ci, co, k, s, 'same', 1, bias=True)
+        mine.load_state_dict(ref.state_dict())
+        x = randn_input(13, name, (2, ci, H, W)).requires_grad_(True)
+        y = ref(x)
+        g = randn_input(14, name, tuple(y.shape))
+        y.backward(g)
+        arrays.update({"deconv.%s.y" % name: y.detach().numpy(), "deconv.%s.gx" % name: x.grad.numpy(),
+                       "deconv.%s.gw" % name: ref.ct2d.weight.grad.numpy(), "deconv.%s.gb" % name: ref.ct2d.bias.grad.numpy()})
+        assert torch.allclose(mine(x), y, atol=1e-6)
+    # convbn / deconvbn / Conv2DownUp in train mode (batch statistics + running stats)
+    for name, ctor, args, shape in [
+            ("convbn", D.convbn, (8, 16, 3, 1, 'same', 1), (4, 8, 10, 12)),
+            ("deconvbn", D.deconvbn, (8, 8, 5, 1, 'same', 1), (4, 8, 10, 12)),
+            ("cdu_last", lambda: D.Conv2DownUp(8, 16, 3, True), (), (2, 8, 12, 16)),
+            ("cdu_nolast", lambda: D.Conv2DownUp(16, 8, 5, False), (), (2, 16, 12, 16))]:
+        ref = fill_state_dict(ctor(*args), 15).train()
+        x = randn_input(15, name, shape).requires_grad_(True)
+        y = ref(x)
+        g = randn_input(16, name, tuple(y.shape))
+        y.backward(g)
+        arrays.update({"%s.y" % name: y.detach().numpy(), "%s.gx" % name: x.grad.numpy()})
+        for k, v in ref.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                arrays["%s.state.%s" % (name, k)] = v.numpy().copy()
+        for k, p in ref.named_parameters():
+            if p.grad is not None:  # Conv2DownUp(lastLayer=False) never runs d5
+                arrays["%s.grad.%s" % (name, k)] = p.grad.numpy().copy()
+    save("ops", **arrays)
+
+
+def gen_backbone():
+    from models import densenet as DN
+    from models import dsnet_t2 as D
+    from models import aspp as A
+    arrays = {}
+    ref = fill_state_dict(DN.densenet121(pretrained=False), 21).train()
+    x = rand_input(21, "img", (2, 3, 256, 256))
+    taps = ref(x)
+    for i, t in enumerate(taps):
+        arrays.update(flat("densenet.tap%d" % i, sample(t, 8)))
+    arrays["densenet.norm5.running_mean"] = ref.norm5.running_mean.numpy().copy()
+    mine = R.densenet121()
+    mine.load_state_dict(ref.state_dict())
+    mine.train()
+    for a, b in zip(mine(x), taps):
+        assert torch.allclose(a, b, atol=1e-4, rtol=1e-4), float((a - b).abs().max())
+
+    ref = fill_state_dict(D.piramidNet2(False, 'densenet'), 22).train()
+    x = rand_input(22, "img", (2, 3, 256, 512))
+    outs = ref(x)
+    for i, t in enumerate(outs):
+        arrays.update(flat("pyramid2.out%d" % i, sample(t, 8)))
+    for tag, ctor in (("aspp_a1", lambda: A.build_aspp('densenet_a1', 32)), ("aspp_a3", lambda: A.build_aspp('densenet_a3', 32))):
+        ref = fill_state_dict(ctor(), 23).eval()   # eval: Dropout(0.5) off, running statistics
+        cin = 128 if tag == "aspp_a1" else 512
+        x = randn_input(23, tag, (2, cin, 16, 24)).requires_grad_(True)
+        y = ref(x)
+        y.backward(randn_input(24, tag, tuple(y.shape)))
+        arrays.update(flat(tag + ".y", sample(y, 2)))
+        arrays.update(flat(tag + ".gx", sample(x.grad, 2)))
+    save("backbone", **arrays)
+
+
+def gen_nets():
+    from models import dsnet_t2 as D
+    arrays = {}
+    cfgs = [("mini_a0", dict(aspp=0), '1dcorr'), ("mini_a1", dict(aspp=1), '1dcorr'), ("mini_a2", dict(aspp=2), '1dcorr'),
+            ("mini_a0_2d", dict(aspp=0), '')]
+    for tag, kw, patch in cfgs:
+        cfg = R.CFG(**kw)
+        for mode in ("train", "eval"):
+            if mode == "train" and kw.get("aspp"):
+                continue  # ASPP Dropout(0.5) is stochastic in train mode (models/aspp.py:79,95)
+            ref = fill_state_dict(D.minidsnetExt(cfg, labels=2, pretrained=False, patch_type=patch, backbone='densenet'), 31)
+            ref.train() if mode == "train" else ref.eval()
+            a, b = rand_input(31, "left", (2, 3, 256, 256)), rand_input(31, "right", (2, 3, 256, 256))
+            seg = F.one_hot((rand_input(31, "seg", (2, 256, 256)) > 0.5).long(), 2).permute(0, 3, 1, 2).float()
+            disp = rand_input(31, "disp", (2, 1, 256, 256), 0.0, 8.0)
+            outs = ref(a, b)
+            loss = train_loss(outs, seg, disp)
+            loss.backward()
+            p = "%s.%s" % (tag, mode)
+            for i, name in enumerate(("seg1", "disp", "seg2")):
+                arrays.update(flat("%s.%s" % (p, name), sample(outs[i], 8)))
+            arrays["%s.loss" % p] = np.float64(loss.item())
+            for k, v in grad_norms(ref).items():
+                arrays["%s.gnorm.%s" % (p, k)] = v
+            if mode == "train":
+                arrays["%s.rm.norm5" % p] = ref.resnet_features.resnet_features.norm5.running_mean.numpy().copy()
+                arrays["%s.rv.norm5" % p] = ref.resnet_features.resnet_features.norm5.running_var.numpy().copy()
+            # the oracle restatement must reproduce the reference here and now
+            mine = R.minidsnetExt(cfg, labels=2, patch_type=patch)
+            mine.load_state_dict(ref.state_dict() if mode == "eval" else fill_state_dict(
+                D.minidsnetExt(cfg, labels=2, pretrained=False, patch_type=patch, backbone='densenet'), 31).state_dict())
+            mine.train() if mode == "train" else mine.eval()
+            mo = mine(a, b)
+            for x, y in zip(mo, outs):
+                err = float((x - y).abs().max())
+                assert err < 2e-4, (tag, mode, err)
+            print(tag, mode, "oracle==reference, loss", loss.item())
+    arrays["meta.corr"] = np.array("assumed-semantics")
+    save("nets", **arrays)
+
+
+if __name__ == "__main__":
+    _install_stubs()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["ops", "backbone", "nets"]
+    if "ops" in which:
+        gen_ops()
+    if "backbone" in which:
+        gen_backbone()
+    if "nets" in which:
+        gen_nets()

@@ -1,0 +1,70 @@
+"""ctypes binding of libsdhip.so — the only way the package reaches the GPU.
+
+There is no CPU or eager-PyTorch fallback: if the shared library is missing or
+fails to load, importing this module raises.  `import torch` happens first on
+purpose: libsdhip.so needs `libamdhip64.so.7` by soname and must bind to the HIP
+runtime PyTorch-ROCm has already mapped, so that stream handles and device
+pointers are shared between the two.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdhip.so")
+
+F32, BF16 = 0, 1
+
+
+class SdhipError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libsdhip.so not found at %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc, gfx950). This package has no fallback path." % LIB_PATH)
+
+_lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+_p, _i, _f, _d, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_long
+_lib.sdhip_last_error.restype = ctypes.c_char_p
+_lib.sdhip_abi_version.restype = _i
+
+# name -> argtypes; every entry of include/sdhip.h is listed here (tests/test_abi.py checks).
+SIGNATURES = {
+    "sdhip_corr_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_corr_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+}
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(_lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = _i
+
+
+def abi_version():
+    return _lib.sdhip_abi_version()
+
+
+def call(name, *args):
+    """Invoke a C entry point; raise SdhipError with the library's message on failure."""
+    rc = getattr(_lib, name)(*args)
+    if rc != 0:
+        raise SdhipError("%s failed (%d): %s" % (name, rc, _lib.sdhip_last_error().decode()))
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise SdhipError("unsupported dtype %s (f32 and bf16 only)" % t.dtype)
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)

@@ -1,0 +1,93 @@
+// sdhip — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// Everything here is wave64 / MFMA specific; there is no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/sdhip.h"
+
+#define SDHIP_WAVE 64
+
+typedef unsigned short bf16_t;  // raw bf16 bits (storage type)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- error plumbing (thread-local last error, never abort) -----------------
+void sdhip_set_error(const char* fmt, ...);
+#define SDHIP_FAIL(code, ...) do { sdhip_set_error(__VA_ARGS__); return (code); } while (0)
+#define SDHIP_CHECK_ARG(cond, ...) do { if (!(cond)) SDHIP_FAIL(SDHIP_ERR_ARG, __VA_ARGS__); } while (0)
+#define SDHIP_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); \
+    if (e__ != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "%s: launch failed: %s", __func__, hipGetErrorString(e__)); } while (0)
+
+// ---- bf16 <-> f32 ------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __builtin_bit_cast(float, ((unsigned int)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // RNE, NaN-safe (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(unsigned int u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bfhi(unsigned int u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kPer16B = 4;
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float rnd(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kPer16B = 8;
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
+};
+
+// unpack a 16-byte chunk into floats (4 for f32, 8 for bf16) and back
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void unpack(const u32x4& u, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, u[i]);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* f) {
+    u32x4 u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = __builtin_bit_cast(unsigned int, f[i]);
+    return u;
+  }
+};
+template <> struct Chunk<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void unpack(const u32x4& u, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bflo(u[i]); f[2 * i + 1] = bfhi(u[i]); }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* f) {
+    u32x4 u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+    return u;
+  }
+};
+
+// ---- wave64 reductions (DPP-free, shuffle based) --------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int sdhip_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -31,14 +31,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void corr_fwd_kernel(
     const T* __restrict__ in1, const T* __restrict__ in2, T* __restrict__ out,
     int B, int H, int W, int C, int ld_in, int PH, int PW, int dil, int ld_out) {
   const int lane = threadIdx.x & 63;
-  const long pix = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const long npix = (long)B * H * W;
-  if (pix >= npix) return;  // wave-uniform
-  const int w = (int)(pix % W);
-  const int h = (int)((pix / W) % H);
-  const long b = pix / ((long)W * H);
-  const T* a_ptr = in1 + pix * ld_in;
-  T* o_ptr = out + pix * ld_out;
+  const int pix = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);  // B*H*W < 2^31 (host-checked)
+  if (pix >= B * H * W) return;  // wave-uniform
+  const int w = pix % W;
+  const int h = (pix / W) % H;
+  const int b = pix / (W * H);
+  const T* a_ptr = in1 + (long)pix * ld_in;
+  T* o_ptr = out + (long)pix * ld_out;
   constexpr int V = VEC ? Chunk<T>::N : 1;
   const int rh = PH / 2, rw = PW / 2;
 
@@ -48,7 +47,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void corr_fwd_kernel(
       const int w2 = w + (pw - rw) * dil;
       float acc = 0.f;
       if (h2 >= 0 && h2 < H && w2 >= 0 && w2 < W) {  // wave-uniform
-        const T* b_ptr = in2 + ((b * H + h2) * (long)W + w2) * ld_in;
+        const T* b_ptr = in2 + (long)((b * H + h2) * W + w2) * ld_in;
         for (int c = lane * V; c < C; c += 64 * V) {
           if constexpr (VEC) {
             u32x4 av = *reinterpret_cast<const u32x4*>(a_ptr + c);
@@ -74,12 +73,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void corr_bwd_kernel(
     T* __restrict__ gin1, T* __restrict__ gin2,
     int B, int H, int W, int C, int ld_in, int PH, int PW, int dil, int ld_out) {
   const int lane = threadIdx.x & 63;
-  const long pix = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const long npix = (long)B * H * W;
-  if (pix >= npix) return;
-  const int w = (int)(pix % W);
-  const int h = (int)((pix / W) % H);
-  const long b = pix / ((long)W * H);
+  const int pix = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (pix >= B * H * W) return;
+  const int w = pix % W;
+  const int h = (pix / W) % H;
+  const int b = pix / (W * H);
   constexpr int V = VEC ? Chunk<T>::N : 1;
   const int rh = PH / 2, rw = PW / 2;
 
@@ -95,8 +93,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void corr_bwd_kernel(
         {
           const int h2 = h + dy, w2 = w + dx;
           if (h2 >= 0 && h2 < H && w2 >= 0 && w2 < W) {
-            const float g = Elem<T>::ld(gout + pix * ld_out + p);
-            const T* src = in2 + ((b * H + h2) * (long)W + w2) * ld_in + c;
+            const float g = Elem<T>::ld(gout + (long)pix * ld_out + p);
+            const T* src = in2 + (long)((b * H + h2) * W + w2) * ld_in + c;
             if constexpr (VEC) {
               float f[V];
               Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(src), f);
@@ -111,7 +109,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void corr_bwd_kernel(
         {
           const int h1 = h - dy, w1 = w - dx;
           if (h1 >= 0 && h1 < H && w1 >= 0 && w1 < W) {
-            const long q = (b * H + h1) * (long)W + w1;
+            const long q = (b * H + h1) * W + w1;
             const float g = Elem<T>::ld(gout + q * ld_out + p);
             const T* src = in1 + q * ld_in + c;
             if constexpr (VEC) {
@@ -127,11 +125,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void corr_bwd_kernel(
       }
     }
     if constexpr (VEC) {
-      *reinterpret_cast<u32x4*>(gin1 + pix * ld_in + c) = Chunk<T>::pack(g1);
-      *reinterpret_cast<u32x4*>(gin2 + pix * ld_in + c) = Chunk<T>::pack(g2);
+      *reinterpret_cast<u32x4*>(gin1 + (long)pix * ld_in + c) = Chunk<T>::pack(g1);
+      *reinterpret_cast<u32x4*>(gin2 + (long)pix * ld_in + c) = Chunk<T>::pack(g2);
     } else {
-      Elem<T>::st(gin1 + pix * ld_in + c, g1[0]);
-      Elem<T>::st(gin2 + pix * ld_in + c, g2[0]);
+      Elem<T>::st(gin1 + (long)pix * ld_in + c, g1[0]);
+      Elem<T>::st(gin2 + (long)pix * ld_in + c, g2[0]);
     }
   }
 }
@@ -149,6 +147,7 @@ int check_common(int B, int H, int W, int C, int ld_in, int PH, int PW, int dil,
   SDHIP_CHECK_ARG(dil >= 1, "corr: dilation_patch must be >= 1");
   SDHIP_CHECK_ARG(ld_in >= C && ld_out >= PH * PW, "corr: pixel stride smaller than channel count");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "corr: unknown dtype %d", dtype);
+  SDHIP_CHECK_ARG((long)B * H * W < (1L << 31), "corr: more than 2^31 pixels");
   return 0;
 }
 

@@ -53,15 +53,17 @@ template <> struct Elem<bf16_t> {
 template <typename T> struct Chunk;
 template <> struct Chunk<float> {
   static constexpr int N = 4;
+  // NB: bit_cast the WHOLE vector; __builtin_bit_cast on a vector-element lvalue (u[i]) reads element 0 (hipcc 7.2).
   static __device__ __forceinline__ void unpack(const u32x4& u, float* f) {
+    const f32x4 v = __builtin_bit_cast(f32x4, u);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, u[i]);
+    for (int i = 0; i < 4; ++i) f[i] = v[i];
   }
   static __device__ __forceinline__ u32x4 pack(const float* f) {
-    u32x4 u;
+    f32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) u[i] = __builtin_bit_cast(unsigned int, f[i]);
-    return u;
+    for (int i = 0; i < 4; ++i) v[i] = f[i];
+    return __builtin_bit_cast(u32x4, v);
   }
 };
 template <> struct Chunk<bf16_t> {

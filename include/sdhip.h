@@ -67,6 +67,92 @@ int sdhip_corr_bwd(const void* in1, const void* in2, const void* gout,
                    int PH, int PW, int dil_patch, int ld_out,
                    int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Direct 2-D convolution (im2col-free, LDS-staged halo tiles, MFMA contraction).
+ *
+ * Replaces ATen/cuDNN under conv2dSame.forward (models/torch_model.py:268-281),
+ * the stride-1 ConvTranspose2dSame.forward (models/torch_model.py:320-349), the
+ * DenseNet nn.Conv2d layers (models/densenet.py:25-93,131-245) and ASPP
+ * (models/aspp.py:7-32).  Weights are consumed in a packed layout produced by
+ * sdhip_conv_pack_weights from the module's f32 parameter:
+ *     packed[q][t][m][c] = W(m, k = q*CK + c, tap t or T-1-t),  zero padded,
+ *     CK = 64 (bf16) / 32 (f32), m < roundup(M,16)
+ * with (stride_m, stride_k, flip) selecting which parameter axis is the output
+ * ("m") and which the reduction ("k") axis:
+ *     Conv2d        weight (Cout,Cin,kh,kw): forward   M=Cout K=Cin sm=Cin*T sk=T    flip=0
+ *                                            data grad M=Cin  K=Cout sm=T     sk=Cin*T flip=1
+ *     ConvTranspose2d weight (Cin,Cout,kh,kw) (stride 1, run as a correlation):
+ *                                            forward   M=Cout K=Cin sm=T     sk=Cout*T flip=1
+ *                                            data grad M=Cin  K=Cout sm=Cout*T sk=T    flip=0
+ * ------------------------------------------------------------------------- */
+long sdhip_conv_packed_elems(int M, int K, int T, int dtype);
+int sdhip_conv_pack_weights(const float* src, void* dst, int M, int K, int T,
+                            long stride_m, long stride_k, int flip, int dtype, void* stream);
+/* Inverse of the packing for the f32 gradient buffer written by sdhip_conv2d_wgrad:
+ * grad(m,k,t) (+)= acc[k/CK][flip ? T-1-t : t][m][k%CK]. */
+int sdhip_conv_unpack_wgrad(const float* acc, float* grad, int M, int K, int T,
+                            long stride_m, long stride_k, int flip, int accumulate, int dtype, void* stream);
+
+/* y[b,oh,ow,m] = act( bias[m] + sum_{t,k} W[m,k,t] * pro(x)[b, oh*stride + kh*dil - pad_t, ow*stride + kw*dil - pad_l, k] )
+ *   pro(x) = x, or relu?(x*in_scale[g][k] + in_shift[g][k]) when in_scale != NULL (the BatchNorm+ReLU
+ *            that precedes the conv, models/densenet.py:41-45,75-93); zero padding is applied AFTER pro;
+ *   g      = b / (B/groups): statistics group of image b (left/right tower passes share a launch);
+ *   stats  : if non-NULL, f64 [groups][2][Cout]; the kernel ADDS sum(y) and sum(y^2) over pixels
+ *            (of the stored, rounded values) — the batch statistics of the BatchNorm that follows;
+ *   act    : 0 none, 1 ReLU, 2 sigmoid;  accumulate != 0: y += result.
+ * (pad_t, pad_l) is the top/left padding; bottom/right padding is implied by (Ho, Wo)
+ * (TF-"same" padding of models/torch_model.py:276-281 is asymmetric for stride 2). */
+int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
+                     const float* bias, const float* in_scale, const float* in_shift, double* stats,
+                     int B, int H, int W, int Cin, int ldx,
+                     int Ho, int Wo, int Cout, int ldy,
+                     int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                     int in_relu, int groups, int act, int accumulate,
+                     int dtype, void* stream);
+/* dW (packed f32, zeroed here) = sum over pixels of dy (x) pro(x); dbias[m] = sum dy (optional). */
+int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* dbias,
+                       const float* in_scale, const float* in_shift,
+                       int B, int H, int W, int Cin, int ldx,
+                       int Ho, int Wo, int Cout, int lddy,
+                       int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                       int in_relu, int groups, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * BatchNorm2d in training mode (+ ReLU / sigmoid / skip add), decomposed so the
+ * statistics ride on the producing conv and the normalisation on the consumer.
+ * Replaces nn.BatchNorm2d as used at models/dsnet_t2.py:16-117,
+ * models/densenet.py:25-128, models/aspp.py:7-32; statistics semantics as in
+ * sync_batchnorm/batchnorm.py:114-126.  Tensors are [npix][C] row views with a
+ * pixel stride; rows of statistics group g are the g-th npix/groups rows.
+ * ------------------------------------------------------------------------- */
+/* stats[g][0][c] += sum x, stats[g][1][c] += sum x^2 (f64). */
+int sdhip_channel_stats(const void* x, int ldx, double* stats, long npix, int C, int groups,
+                        int zero_first, int dtype, void* stream);
+/* Train (stats != NULL): mean = S1/count, var = S2/count - mean^2 (biased), scale = gamma*invstd,
+ * shift = beta - mean*scale; running_mean/var updated in place group by group with `momentum`
+ * (running_var unbiased).  Eval (stats == NULL): scale/shift from the running statistics. */
+int sdhip_bn_finalize(const double* stats, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var,
+                      float* scale, float* shift, float* mean_out, float* invstd_out,
+                      int C, int groups, double count, float eps, float momentum, void* stream);
+/* (dscale,dshift)[g][c] -> dgamma[c], dbeta[c] and dstats[g][2][c] (gradient w.r.t. S1, S2; zero in eval). */
+int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gamma,
+                          const float* mean, const float* invstd,
+                          float* dgamma, float* dbeta, double* dstats,
+                          int C, int groups, double count, int train, void* stream);
+/* y = act(x*scale[g][c] + shift[g][c]) (+ res). scale/shift may be NULL (identity). */
+int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const void* res, int ldr,
+                     const float* scale, const float* shift, long npix, int C, int groups, int act,
+                     int dtype, void* stream);
+/* act: 0 none, 1 ReLU, 2 sigmoid, 4 sigmoid with x holding the sigmoid OUTPUT.
+ * gx = gy*act'*scale (if gx != NULL); dscale = sum gy*act'*x, dshift = sum gy*act' (if non-NULL; zeroed here). */
+int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
+                         const float* scale, const float* shift, float* dscale, float* dshift,
+                         long npix, int C, int groups, int act, int dtype, void* stream);
+/* gout = gin + dstats[g][0][c] + 2*x*dstats[g][1][c]: the gradient that flows through the batch statistics. */
+int sdhip_stats_fix(const void* gin, int ldgi, const void* x, int ldx, void* gout, int ldgo,
+                    const double* dstats, long npix, int C, int groups, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,11 +36,27 @@ _lib.sdhip_abi_version.restype = _i
 SIGNATURES = {
     "sdhip_corr_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_corr_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_conv_pack_weights": [_p, _p, _i, _i, _i, _l, _l, _i, _i, _p],
+    "sdhip_conv_unpack_wgrad": [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p],
+    "sdhip_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 20 + [_p],
+    "sdhip_conv2d_wgrad": [_p, _p, _p, _p, _p, _p] + [_i] * 18 + [_p],
+    "sdhip_channel_stats": [_p, _i, _p, _l, _i, _i, _i, _i, _p],
+    "sdhip_bn_finalize": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _d, _f, _f, _p],
+    "sdhip_bn_finalize_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _d, _i, _p],
+    "sdhip_affine_act": [_p, _i, _p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _i, _p],
+    "sdhip_affine_act_bwd": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p],
+    "sdhip_stats_fix": [_p, _i, _p, _i, _p, _i, _p, _l, _i, _i, _i, _p],
 }
+_lib.sdhip_conv_packed_elems.argtypes = [_i, _i, _i, _i]
+_lib.sdhip_conv_packed_elems.restype = _l
 for _name, _args in SIGNATURES.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
     _fn.restype = _i
+
+
+def packed_elems(M, K, T, dt):
+    return _lib.sdhip_conv_packed_elems(M, K, T, dt)
 
 
 def abi_version():

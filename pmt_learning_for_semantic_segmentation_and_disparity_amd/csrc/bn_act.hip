@@ -1,0 +1,419 @@
+// BatchNorm (train-mode batch statistics) + activation, decomposed for fusion, for gfx950.
+//
+// Replaces nn.BatchNorm2d (+ nn.ReLU / skip add) as used by convbn / deconvbn /
+// Conv2DownUp (models/dsnet_t2.py:16-117), the DenseNet layers
+// (models/densenet.py:25-93,119-128) and ASPP (models/aspp.py:7-32); semantics of
+// the statistics as restated in sync_batchnorm/batchnorm.py:114-126 (sum, sum of
+// squares, count -> mean, biased variance for normalisation, unbiased for
+// running_var, momentum 0.1).
+//
+//   statistics  S[g] = (sum x, sum x^2) per channel and statistics group g (f64; produced by the
+//               conv epilogue or by sdhip_channel_stats; a "group" is a sub-batch that the
+//               reference normalises separately, e.g. the left and the right tower pass)
+//   finalize    scale = gamma * invstd, shift = beta - mean * scale           (tiny, per channel)
+//   apply       y = act(x * scale + shift) (+ residual)                        (HBM bound, 16 B/lane)
+//   backward    gx = gy * act' * scale,  dscale = sum gy*act'*x,  dshift = sum gy*act'   (one pass)
+//               finalize_bwd: (dscale, dshift) -> dgamma, dbeta, dS
+//               stats_fix   : g += dS1 + 2 * x * dS2      (gradient through the statistics)
+//
+// All elementwise kernels view a tensor as [pixels][C] rows with pixel stride ld.
+#include "sdhip_common.h"
+
+namespace {
+
+struct RowGeom {  // how a 256-thread block walks a [npix][C] matrix
+  int tx, ty;     // threads across channel units / across pixels
+  int units;      // channel units per row (16-byte chunks, or single elements in scalar mode)
+};
+
+inline RowGeom row_geom(int units) {
+  RowGeom r;
+  r.units = units;
+  r.tx = units < 64 ? units : 64;
+  r.ty = 256 / r.tx;
+  return r;
+}
+
+template <typename T, bool VEC> struct Unit {
+  static constexpr int N = VEC ? Chunk<T>::N : 1;
+  static __device__ __forceinline__ void load(const T* p, float* f) {
+    if constexpr (VEC) Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(p), f);
+    else f[0] = Elem<T>::ld(p);
+  }
+  static __device__ __forceinline__ void store(T* p, const float* f) {
+    if constexpr (VEC) *reinterpret_cast<u32x4*>(p) = Chunk<T>::pack(f);
+    else Elem<T>::st(p, f[0]);
+  }
+};
+
+// y = act(x*scale + shift) (+ res);  grid: (pixel slabs, unit groups, stat groups)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                         const T* __restrict__ res, int ldr,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int C, long npix_g, int act, RowGeom rg) {
+  constexpr int N = Unit<T, VEC>::N;
+  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  const int u = blockIdx.y * rg.tx + tx;
+  if (ty >= rg.ty || u >= rg.units) return;
+  const int g = blockIdx.z, c0 = u * N;
+  float sc[N], sf[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { sc[e] = scale ? scale[g * C + c0 + e] : 1.f; sf[e] = shift ? shift[g * C + c0 + e] : 0.f; }
+  const long base = (long)g * npix_g;
+  for (long pix = (long)blockIdx.x * rg.ty + ty; pix < npix_g; pix += (long)gridDim.x * rg.ty) {
+    float f[N], r[N];
+    Unit<T, VEC>::load(x + (base + pix) * ldx + c0, f);
+    if (res) Unit<T, VEC>::load(res + (base + pix) * ldr + c0, r);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      float v = fmaf(f[e], sc[e], sf[e]);
+      if (act == 1) v = fmaxf(v, 0.f);
+      else if (act == 2) v = 1.f / (1.f + __expf(-v));
+      if (res) v += r[e];
+      f[e] = v;
+    }
+    Unit<T, VEC>::store(y + (base + pix) * ldy + c0, f);
+  }
+}
+
+// gx = gy * act'(x*scale+shift) * scale;  dscale += sum gy*act'*x;  dshift += sum gy*act'
+// mode 0: both; mode 1: only the reductions (gx not written)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* __restrict__ gy, int ldg, const T* __restrict__ x, int ldx,
+                                                             T* __restrict__ gx, int ldgx,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             float* __restrict__ dscale, float* __restrict__ dshift,
+                                                             int C, long npix_g, int act, RowGeom rg) {
+  constexpr int N = Unit<T, VEC>::N;
+  __shared__ float red[2][256 * (VEC ? Chunk<T>::N : 1)];
+  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  const int u = blockIdx.y * rg.tx + tx;
+  const bool live = ty < rg.ty && u < rg.units;
+  const int g = blockIdx.z, c0 = u * N;
+  float sc[N], sf[N], a1[N], a2[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    sc[e] = (live && scale) ? scale[g * C + c0 + e] : 1.f;
+    sf[e] = (live && shift) ? shift[g * C + c0 + e] : 0.f;
+    a1[e] = 0.f; a2[e] = 0.f;
+  }
+  const long base = (long)g * npix_g;
+  if (live) {
+    for (long pix = (long)blockIdx.x * rg.ty + ty; pix < npix_g; pix += (long)gridDim.x * rg.ty) {
+      float gv[N], xv[N];
+      Unit<T, VEC>::load(gy + (base + pix) * ldg + c0, gv);
+      Unit<T, VEC>::load(x + (base + pix) * ldx + c0, xv);
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        const float z = fmaf(xv[e], sc[e], sf[e]);
+        float gm = gv[e];
+        if (act == 1) gm = z > 0.f ? gm : 0.f;
+        else if (act == 2) { const float sg = 1.f / (1.f + __expf(-z)); gm *= sg * (1.f - sg); }
+        else if (act == 4) gm *= z * (1.f - z);  // x holds the sigmoid OUTPUT
+        a1[e] = fmaf(gm, xv[e], a1[e]);
+        a2[e] += gm;
+        gv[e] = gm * sc[e];
+      }
+      if (gx) Unit<T, VEC>::store(gx + (base + pix) * ldgx + c0, gv);
+    }
+  }
+  if (!dscale) return;  // uniform
+  // reduce over the ty rows of the block, then one atomic per channel
+#pragma unroll
+  for (int e = 0; e < N; ++e) { red[0][threadIdx.x * N + e] = a1[e]; red[1][threadIdx.x * N + e] = a2[e]; }
+  __syncthreads();
+  if (ty == 0 && u < rg.units) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int r = 0; r < rg.ty; ++r) { s1 += red[0][(r * rg.tx + tx) * N + e]; s2 += red[1][(r * rg.tx + tx) * N + e]; }
+      atomicAdd(dscale + g * C + c0 + e, s1);
+      atomicAdd(dshift + g * C + c0 + e, s2);
+    }
+  }
+}
+
+// g_out = g_in + dS1 + 2 * x * dS2   (dS is [G][2][C], f64 like the statistics it is the gradient of)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void stats_fix_kernel(const T* __restrict__ gin, int ldgi, const T* __restrict__ x, int ldx,
+                                                        T* __restrict__ gout, int ldgo, const double* __restrict__ dS,
+                                                        int C, long npix_g, RowGeom rg) {
+  constexpr int N = Unit<T, VEC>::N;
+  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  const int u = blockIdx.y * rg.tx + tx;
+  if (ty >= rg.ty || u >= rg.units) return;
+  const int g = blockIdx.z, c0 = u * N;
+  float a[N], b2[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { a[e] = (float)dS[((long)g * 2 + 0) * C + c0 + e]; b2[e] = (float)(2.0 * dS[((long)g * 2 + 1) * C + c0 + e]); }
+  const long base = (long)g * npix_g;
+  for (long pix = (long)blockIdx.x * rg.ty + ty; pix < npix_g; pix += (long)gridDim.x * rg.ty) {
+    float gv[N], xv[N];
+    Unit<T, VEC>::load(gin + (base + pix) * ldgi + c0, gv);
+    Unit<T, VEC>::load(x + (base + pix) * ldx + c0, xv);
+#pragma unroll
+    for (int e = 0; e < N; ++e) gv[e] = gv[e] + fmaf(xv[e], b2[e], a[e]);
+    Unit<T, VEC>::store(gout + (base + pix) * ldgo + c0, gv);
+  }
+}
+
+// S[g][0][c] += sum x, S[g][1][c] += sum x^2  (f64 atomics)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, int ldx, double* __restrict__ S,
+                                                            int C, long npix_g, RowGeom rg) {
+  constexpr int N = Unit<T, VEC>::N;
+  __shared__ float red[2][256 * (VEC ? Chunk<T>::N : 1)];
+  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  const int u = blockIdx.y * rg.tx + tx;
+  const bool live = ty < rg.ty && u < rg.units;
+  const int g = blockIdx.z, c0 = u * N;
+  float a1[N], a2[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+  const long base = (long)g * npix_g;
+  if (live) {
+    for (long pix = (long)blockIdx.x * rg.ty + ty; pix < npix_g; pix += (long)gridDim.x * rg.ty) {
+      float xv[N];
+      Unit<T, VEC>::load(x + (base + pix) * ldx + c0, xv);
+#pragma unroll
+      for (int e = 0; e < N; ++e) { a1[e] += xv[e]; a2[e] = fmaf(xv[e], xv[e], a2[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < N; ++e) { red[0][threadIdx.x * N + e] = a1[e]; red[1][threadIdx.x * N + e] = a2[e]; }
+  __syncthreads();
+  if (ty == 0 && u < rg.units) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      double s1 = 0., s2 = 0.;
+      for (int r = 0; r < rg.ty; ++r) { s1 += red[0][(r * rg.tx + tx) * N + e]; s2 += red[1][(r * rg.tx + tx) * N + e]; }
+      atomicAdd(S + ((long)g * 2 + 0) * C + c0 + e, s1);
+      atomicAdd(S + ((long)g * 2 + 1) * C + c0 + e, s2);
+    }
+  }
+}
+
+// ---- per-channel finalize (tiny) ------------------------------------------------
+// train: S -> mean, invstd, scale, shift, running stats (groups applied in order)
+__global__ void bn_finalize_kernel(const double* __restrict__ S, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, int C, int G, double count, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  if (S == nullptr) {  // eval mode: running statistics
+    const float inv = 1.f / sqrtf(rvar[c] + eps);
+    for (int g = 0; g < G; ++g) {
+      scale[g * C + c] = gm * inv;
+      shift[g * C + c] = bt - rmean[c] * gm * inv;
+      if (mean_out) { mean_out[g * C + c] = rmean[c]; invstd_out[g * C + c] = inv; }
+    }
+    return;
+  }
+  float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+  for (int g = 0; g < G; ++g) {
+    const double mu = S[((long)g * 2 + 0) * C + c] / count;
+    double var = S[((long)g * 2 + 1) * C + c] / count - mu * mu;
+    if (var < 0.) var = 0.;
+    const float inv = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gm * inv;
+    scale[g * C + c] = sc;
+    shift[g * C + c] = (float)((double)bt - mu * (double)sc);
+    mean_out[g * C + c] = (float)mu;
+    invstd_out[g * C + c] = inv;
+    const double unb = count > 1. ? var * count / (count - 1.) : var;
+    rm = (1.f - momentum) * rm + momentum * (float)mu;
+    rv = (1.f - momentum) * rv + momentum * (float)unb;
+  }
+  if (rmean) { rmean[c] = rm; rvar[c] = rv; }
+}
+
+// (dscale, dshift)[G][C] -> dgamma[C], dbeta[C] (summed over groups), dS[G][2][C]
+__global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, double* __restrict__ dS,
+                                       int C, int G, double count, int train) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float gm = gamma ? gamma[c] : 1.f;
+  float dg = 0.f, db = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float ds = dscale[g * C + c], dh = dshift[g * C + c];
+    const float mu = mean[g * C + c], inv = invstd[g * C + c];
+    const float t = ds - mu * dh;       // d/d(gamma*invstd) collected
+    dg += inv * t;
+    db += dh;
+    if (dS) {
+      if (train) {
+        const double dinv = (double)gm * t;
+        const double dvar = -0.5 * dinv * (double)inv * inv * inv;
+        const double dmu = -(double)gm * inv * dh - 2.0 * mu * dvar;
+        dS[((long)g * 2 + 0) * C + c] = dmu / count;
+        dS[((long)g * 2 + 1) * C + c] = dvar / count;
+      } else {
+        dS[((long)g * 2 + 0) * C + c] = 0.;
+        dS[((long)g * 2 + 1) * C + c] = 0.;
+      }
+    }
+  }
+  if (dgamma) dgamma[c] = dg;
+  if (dbeta) dbeta[c] = db;
+}
+
+template <typename T>
+bool vec_rows(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+  const int n = Chunk<T>::N;
+  if (C % n) return false;
+  for (int l : lds) if (l % n) return false;
+  for (const void* p : ptrs) if (p && ((uintptr_t)p & 15)) return false;
+  return true;
+}
+
+struct Plan { RowGeom rg; dim3 grid; };
+Plan plan(int units, long npix_g, int G) {
+  Plan p;
+  p.rg = row_geom(units);
+  const int gy = sdhip_cdiv(units, p.rg.tx);
+  long gx = (npix_g + p.rg.ty - 1) / p.rg.ty;
+  const long cap = 2048 / ((long)gy * G) > 0 ? 2048 / ((long)gy * G) : 1;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  p.grid = dim3((unsigned)gx, (unsigned)gy, (unsigned)G);
+  return p;
+}
+
+int check_rows(const char* who, long npix, int C, int G, int dtype) {
+  SDHIP_CHECK_ARG(npix > 0 && C > 0 && G >= 1 && npix % G == 0, "%s: bad shape npix=%ld C=%d groups=%d", who, npix, C, G);
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "%s: unknown dtype %d", who, dtype);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const void* res, int ldr,
+                                const float* scale, const float* shift, long npix, int C, int groups, int act,
+                                int dtype, void* stream) {
+  const int G = groups;
+  if (int rc = check_rows("affine_act", npix, C, G, dtype)) return rc;
+  SDHIP_CHECK_ARG(x && y && ldx >= C && ldy >= C && (!res || ldr >= C), "affine_act: bad pointers/strides");
+  hipStream_t s = (hipStream_t)stream;
+#define ARGS(T) (const T*)x, ldx, (T*)y, ldy, (const T*)res, ldr, scale, shift, C, npix / G, act
+  if (dtype == SDHIP_F32) {
+    const bool v = vec_rows<float>(C, {ldx, ldy, res ? ldr : 0}, {x, y, res});
+    Plan pl = plan(v ? C / 4 : C, npix / G, G);
+    if (v) hipLaunchKernelGGL((affine_act_kernel<float, true>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+    else hipLaunchKernelGGL((affine_act_kernel<float, false>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+  } else {
+    const bool v = vec_rows<bf16_t>(C, {ldx, ldy, res ? ldr : 0}, {x, y, res});
+    Plan pl = plan(v ? C / 8 : C, npix / G, G);
+    if (v) hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+    else hipLaunchKernelGGL((affine_act_kernel<bf16_t, false>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+  }
+#undef ARGS
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
+                                    const float* scale, const float* shift, float* dscale, float* dshift,
+                                    long npix, int C, int groups, int act, int dtype, void* stream) {
+  const int G = groups;
+  if (int rc = check_rows("affine_act_bwd", npix, C, G, dtype)) return rc;
+  SDHIP_CHECK_ARG(gy && x && ldg >= C && ldx >= C && (!gx || ldgx >= C), "affine_act_bwd: bad pointers/strides");
+  SDHIP_CHECK_ARG((dscale == nullptr) == (dshift == nullptr), "affine_act_bwd: dscale/dshift must come together");
+  hipStream_t s = (hipStream_t)stream;
+  if (dscale) {
+    if (hipMemsetAsync(dscale, 0, sizeof(float) * (size_t)G * C, s) != hipSuccess ||
+        hipMemsetAsync(dshift, 0, sizeof(float) * (size_t)G * C, s) != hipSuccess)
+      SDHIP_FAIL(SDHIP_ERR_LAUNCH, "affine_act_bwd: memset failed");
+  }
+#define ARGS(T) (const T*)gy, ldg, (const T*)x, ldx, (T*)gx, ldgx, scale, shift, dscale, dshift, C, npix / G, act
+  if (dtype == SDHIP_F32) {
+    const bool v = vec_rows<float>(C, {ldg, ldx, gx ? ldgx : 0}, {gy, x, gx});
+    Plan pl = plan(v ? C / 4 : C, npix / G, G);
+    if (v) hipLaunchKernelGGL((affine_act_bwd_kernel<float, true>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+    else hipLaunchKernelGGL((affine_act_bwd_kernel<float, false>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+  } else {
+    const bool v = vec_rows<bf16_t>(C, {ldg, ldx, gx ? ldgx : 0}, {gy, x, gx});
+    Plan pl = plan(v ? C / 8 : C, npix / G, G);
+    if (v) hipLaunchKernelGGL((affine_act_bwd_kernel<bf16_t, true>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+    else hipLaunchKernelGGL((affine_act_bwd_kernel<bf16_t, false>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+  }
+#undef ARGS
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_stats_fix(const void* gin, int ldgi, const void* x, int ldx, void* gout, int ldgo,
+                               const double* dS, long npix, int C, int groups, int dtype, void* stream) {
+  const int G = groups;
+  if (int rc = check_rows("stats_fix", npix, C, G, dtype)) return rc;
+  SDHIP_CHECK_ARG(gin && x && gout && dS && ldgi >= C && ldx >= C && ldgo >= C, "stats_fix: bad pointers/strides");
+  hipStream_t s = (hipStream_t)stream;
+#define ARGS(T) (const T*)gin, ldgi, (const T*)x, ldx, (T*)gout, ldgo, dS, C, npix / G
+  if (dtype == SDHIP_F32) {
+    const bool v = vec_rows<float>(C, {ldgi, ldx, ldgo}, {gin, x, gout});
+    Plan pl = plan(v ? C / 4 : C, npix / G, G);
+    if (v) hipLaunchKernelGGL((stats_fix_kernel<float, true>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+    else hipLaunchKernelGGL((stats_fix_kernel<float, false>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+  } else {
+    const bool v = vec_rows<bf16_t>(C, {ldgi, ldx, ldgo}, {gin, x, gout});
+    Plan pl = plan(v ? C / 8 : C, npix / G, G);
+    if (v) hipLaunchKernelGGL((stats_fix_kernel<bf16_t, true>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+    else hipLaunchKernelGGL((stats_fix_kernel<bf16_t, false>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+  }
+#undef ARGS
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_channel_stats(const void* x, int ldx, double* stats, long npix, int C, int groups,
+                                   int zero_first, int dtype, void* stream) {
+  const int G = groups;
+  if (int rc = check_rows("channel_stats", npix, C, G, dtype)) return rc;
+  SDHIP_CHECK_ARG(x && stats && ldx >= C, "channel_stats: bad pointers/strides");
+  hipStream_t s = (hipStream_t)stream;
+  if (zero_first && hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)G * C, s) != hipSuccess)
+    SDHIP_FAIL(SDHIP_ERR_LAUNCH, "channel_stats: memset failed");
+#define ARGS(T) (const T*)x, ldx, stats, C, npix / G
+  if (dtype == SDHIP_F32) {
+    const bool v = vec_rows<float>(C, {ldx}, {x});
+    Plan pl = plan(v ? C / 4 : C, npix / G, G);
+    if (v) hipLaunchKernelGGL((channel_stats_kernel<float, true>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+    else hipLaunchKernelGGL((channel_stats_kernel<float, false>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+  } else {
+    const bool v = vec_rows<bf16_t>(C, {ldx}, {x});
+    Plan pl = plan(v ? C / 8 : C, npix / G, G);
+    if (v) hipLaunchKernelGGL((channel_stats_kernel<bf16_t, true>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+    else hipLaunchKernelGGL((channel_stats_kernel<bf16_t, false>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+  }
+#undef ARGS
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_bn_finalize(const double* stats, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var,
+                                 float* scale, float* shift, float* mean_out, float* invstd_out,
+                                 int C, int groups, double count, float eps, float momentum, void* stream) {
+  SDHIP_CHECK_ARG(C > 0 && groups >= 1 && scale && shift, "bn_finalize: bad arguments");
+  SDHIP_CHECK_ARG(stats || (running_mean && running_var), "bn_finalize: eval mode needs running statistics");
+  SDHIP_CHECK_ARG(!stats || (mean_out && invstd_out && count >= 1.), "bn_finalize: train mode needs mean/invstd outputs and a count");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sdhip_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, gamma, beta,
+                     running_mean, running_var, scale, shift, mean_out, invstd_out, C, groups, count, eps, momentum);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gamma,
+                                     const float* mean, const float* invstd,
+                                     float* dgamma, float* dbeta, double* dstats,
+                                     int C, int groups, double count, int train, void* stream) {
+  SDHIP_CHECK_ARG(C > 0 && groups >= 1 && dscale && dshift && mean && invstd, "bn_finalize_bwd: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(sdhip_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, dscale, dshift,
+                     gamma, mean, invstd, dgamma, dbeta, dstats, C, groups, count, train);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}

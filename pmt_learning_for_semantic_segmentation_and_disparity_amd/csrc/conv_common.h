@@ -1,0 +1,48 @@
+// Shared pieces of the direct (im2col-free) convolution kernels.
+//
+// Data layout
+//   activations : NHWC, pixel stride ld (elements)           -> one pixel = one contiguous run
+//   LDS "row"   : 128 bytes = 8 chunks of 16 B = CK channels  (CK = 64 bf16 / 32 f32)
+//   packed W    : [nq][T][Mpad][CK]  (nq = ceil(K/CK) channel chunks, T = kh*kw taps,
+//                 Mpad = output channels rounded up to 16); row (q,t,m) holds the CK
+//                 reduction-channel weights of output channel m for tap t, zero padded.
+//
+// MFMA orientation: D[M = out channel][N = pixel] = A(weights) x B(pixels); a lane ends up with
+// 4 consecutive output channels of one pixel, i.e. a contiguous 8/16-byte NHWC store.
+// Both operand fragments are one 16-byte LDS read per lane (ds_read_b128):
+//   bf16: v_mfma_f32_16x16x32_bf16, lane (r = l&15, g = l>>4) holds k = 8g..8g+7
+//   f32 : 4 x v_mfma_f32_16x16x4_f32 on the 4 floats of the chunk (k = channel 4g+i in MFMA i);
+//         exact f32 FMA chain, used for the 1e-3 parity path.
+#pragma once
+#include "sdhip_common.h"
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], acc, 0, 0, 0);
+  }
+};
+
+// XOR swizzle of the 16-byte chunk index inside a 128-byte LDS row: 16 consecutive rows read at
+// the same logical chunk land on 16 distinct 16-byte bank slots (conflict-free ds_read_b128).
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + (swz(row, chunk) << 4); }
+
+struct ConvGeom {
+  int B, H, W;        // input  spatial
+  int Ho, Wo;         // output spatial
+  int kh, kw, stride, dil, pad_t, pad_l;
+};
+
+// host-side: channels per 128-byte row
+static inline int conv_ck(int dtype) { return dtype == SDHIP_BF16 ? 64 : 32; }
+static inline int conv_esize(int dtype) { return dtype == SDHIP_BF16 ? 2 : 4; }

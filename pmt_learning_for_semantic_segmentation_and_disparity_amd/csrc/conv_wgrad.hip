@@ -1,0 +1,370 @@
+// Direct 2-D convolution, weight-gradient form, for gfx950 (MI355X).
+//
+//   dW[t][m][k] = sum over (b, oh, ow) of dY[b,oh,ow,m] * Xeff[b, oh*s + kh*d - pad_t, ow*s + kw*d - pad_l, k]
+//
+// (Xeff = X after the optional fused input prologue.)  This is the backward of
+// conv2dSame / ConvTranspose2dSame / nn.Conv2d of the reference
+// (models/torch_model.py:236-349, models/densenet.py:25-93) w.r.t. their weights.
+//
+// The contraction runs over PIXELS, so both MFMA operands must be read
+// pixel-major from channel-major (NHWC) tiles.  The tiles are staged in LDS
+// exactly as in the forward kernel ([pixel][channel], 128-byte rows) and the
+// fragments are fetched with gfx950's transposing LDS read (ds_read_b64_tr_b16),
+// so no transposed copy of the activations is ever made; tap shifts are plain
+// row offsets into the shared halo tile.  A workgroup owns (output-channel block,
+// input-channel chunk, <= 9 taps), keeps those partial sums in registers while it
+// sweeps a strided share of all pixel tiles, and flushes once with f32 atomics
+// into the packed f32 gradient buffer.
+#include "conv_common.h"
+
+namespace {
+
+constexpr int kMaxTaps = 9;  // taps per workgroup (accumulators stay in registers)
+
+struct WgArgs {
+  const void* x; const void* dy; float* dwp; float* dbias;
+  const float* in_scale; const float* in_shift;
+  ConvGeom g;
+  int Cin, ldx, Cout, Mpad, lddy;
+  int in_relu, groups;
+  int tpb, ntg, nq;  // taps per workgroup, tap groups, channel chunks
+  int vec_x, vec_dy;
+};
+
+typedef __attribute__((address_space(3))) bf16x4_t* lds_bf4_ptr;
+
+// 16x16x32 bf16 operand fragment, pixel-major, from a [pixel][channel] LDS image.
+// `rows[h]` is the LDS row (pixel) this lane addresses in half h, i.e. pixel 8g + 4h + ((l&15)>>2);
+// `ch` the first channel of the 16-channel tile.
+__device__ __forceinline__ u32x4 tr_frag(unsigned char* base, int row0, int row1, int ch, int lane) {
+  const int p = lane & 3;                      // 4-channel sub-block this lane addresses
+  const int c = (ch >> 3) + (p >> 1);          // 16-byte chunk
+  const int sub = (p & 1) << 3;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(base + lds_off(row0, c) + sub));
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(base + lds_off(row1, c) + sub));
+  const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+  return u32x4{l2[0], l2[1], h2[0], h2[1]};
+}
+
+template <typename T, int TH, int TW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
+  constexpr int V = Chunk<T>::N;
+  constexpr int CK = 8 * V;                 // channels per LDS row = output-channel block = input-channel chunk
+  constexpr int NTILE = CK / 16;            // 16-channel MFMA tiles per chunk: 4 (bf16) / 2 (f32)
+  constexpr int NCO = NTILE * NTILE / 4;    // output-channel tiles per wave: 4 (bf16) / 1 (f32)
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int KSTEP = BF ? 32 : 4;        // pixels per MFMA k-step
+  static_assert((TH * TW) % 32 == 0, "tile must be whole k-steps");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const ConvGeom& g = p.g;
+  const int s = g.stride, d = g.dil;
+  const int IH = (TH - 1) * s + (g.kh - 1) * d + 1, IW = (TW - 1) * s + (g.kw - 1) * d + 1;
+  const int T_ = g.kh * g.kw;
+  // blockIdx.y -> (output-channel block, channel chunk, tap group)
+  int by = blockIdx.y;
+  const int tgi = by % p.ntg; by /= p.ntg;
+  const int q = by % p.nq;
+  const int mb = by / p.nq;
+  const int t0 = tgi * p.tpb, nt = min(p.tpb, T_ - t0);
+  const int m0 = mb * CK;
+  const int ci_tile = wave % NTILE;          // this wave's 16 input channels of the chunk
+  const int co_tile0 = (wave / NTILE) * NCO;  // first output-channel tile of this wave
+  const int cin_q = min(CK, p.Cin - q * CK);
+  const int cout_m = min(CK, p.Cout - m0);
+  const int shx = (cin_q + CK / 2 - 1) / (CK / 2) == 2 ? 3 : 2;   // data chunks per X row: 8 or 4
+  const int shy = (cout_m + CK / 2 - 1) / (CK / 2) == 2 ? 3 : 2;
+
+  unsigned char* halo = smem;
+  unsigned char* ytile = smem + ((IH * IW * 128 + 15) & ~15);
+
+  f32x4 acc[kMaxTaps][NCO];
+#pragma unroll
+  for (int t = 0; t < kMaxTaps; ++t)
+#pragma unroll
+    for (int mi = 0; mi < NCO; ++mi) acc[t][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;  // bias gradient partial of channel (tid % CK), pixel stripe (tid / CK)
+
+  const int tiles_w = (g.Wo + TW - 1) / TW, tiles_h = (g.Ho + TH - 1) / TH;
+  const int ntiles = g.B * tiles_h * tiles_w;
+  const bool wave_active = ci_tile * 16 < cin_q;  // wave-uniform
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (tiles_h * tiles_w);
+    const int tr = tile - b * tiles_h * tiles_w;
+    const int oh0 = (tr / tiles_w) * TH, ow0 = (tr % tiles_w) * TW;
+    const int ih0 = oh0 * s - g.pad_t, iw0 = ow0 * s - g.pad_l;
+    const int grp = p.groups > 1 ? b / (g.B / p.groups) : 0;
+    const T* xb = (const T*)p.x + (long)b * g.H * g.W * p.ldx;
+    const T* yb = (const T*)p.dy + (long)b * g.Ho * g.Wo * p.lddy;
+    __syncthreads();  // previous tile's fragments are consumed
+    // ---- stage the X halo tile of channel chunk q (same image as the forward kernel) ----
+    for (int i = tid; i < ((IH * IW) << shx); i += 256) {
+      const int pix = i >> shx, c = i & ((1 << shx) - 1);
+      const int ih = pix / IW, iw = pix - ih * IW;
+      const int gh = ih0 + ih, gw = iw0 + iw;
+      const int ch0 = q * CK + c * V;
+      float f[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) f[e] = 0.f;
+      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+      if (gh >= 0 && gh < g.H && gw >= 0 && gw < g.W && ch0 < p.Cin) {
+        const T* src = xb + ((long)gh * g.W + gw) * p.ldx + ch0;
+        if (p.vec_x) {
+          raw = *reinterpret_cast<const u32x4*>(src);
+          if (p.in_scale) Chunk<T>::unpack(raw, f);
+        } else {
+#pragma unroll
+          for (int e = 0; e < V; ++e) if (ch0 + e < p.Cin) f[e] = Elem<T>::ld(src + e);
+        }
+        if (p.in_scale) {
+          const float* sc = p.in_scale + grp * p.Cin + ch0;
+          const float* sf = p.in_shift + grp * p.Cin + ch0;
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            if (ch0 + e < p.Cin) {
+              const float v = fmaf(f[e], sc[e], sf[e]);
+              f[e] = p.in_relu ? fmaxf(v, 0.f) : v;
+            }
+          raw = Chunk<T>::pack(f);
+        } else if (!p.vec_x) {
+          raw = Chunk<T>::pack(f);
+        }
+      }
+      *reinterpret_cast<u32x4*>(halo + lds_off(pix, c)) = raw;
+    }
+    // ---- stage the dY tile of output-channel block mb ----
+    for (int i = tid; i < ((TH * TW) << shy); i += 256) {
+      const int pix = i >> shy, c = i & ((1 << shy) - 1);
+      const int orow = pix / TW, ocol = pix - orow * TW;
+      const int oh = oh0 + orow, ow = ow0 + ocol;
+      const int ch0 = m0 + c * V;
+      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+      if (oh < g.Ho && ow < g.Wo && ch0 < p.Cout) {
+        const T* src = yb + ((long)oh * g.Wo + ow) * p.lddy + ch0;
+        if (p.vec_dy) {
+          raw = *reinterpret_cast<const u32x4*>(src);
+        } else {
+          float f[V];
+#pragma unroll
+          for (int e = 0; e < V; ++e) f[e] = (ch0 + e < p.Cout) ? Elem<T>::ld(src + e) : 0.f;
+          raw = Chunk<T>::pack(f);
+        }
+      }
+      *reinterpret_cast<u32x4*>(ytile + lds_off(pix, c)) = raw;
+    }
+    __syncthreads();
+
+    if (p.dbias && q == 0 && tgi == 0) {  // uniform: bias gradient = column sums of the dY tile
+      const int ch = tid % CK, stripe = tid / CK;
+      if (ch < cout_m) {
+        const int c = ch / V, e = ch % V;
+        for (int pix = stripe; pix < TH * TW; pix += 256 / CK)
+          bsum += Elem<T>::ld(reinterpret_cast<const T*>(ytile + lds_off(pix, c)) + e);
+      }
+    }
+
+    // ---- MFMA over the tile's pixels ----
+    for (int k0 = 0; k0 < TH * TW; k0 += KSTEP) {
+      if constexpr (BF) {
+        // this lane addresses pixels k0 + 8*lg + 4*h + ((l15)>>2), h = 0,1
+        const int pa = k0 + 8 * lg + (l15 >> 2);
+        const int pb = pa + 4;
+        u32x4 af[NCO];
+#pragma unroll
+        for (int mi = 0; mi < NCO; ++mi) af[mi] = tr_frag(ytile, pa, pb, (co_tile0 + mi) * 16, lane);
+        const int ha = ((pa / TW) * s) * IW + (pa % TW) * s;
+        const int hb = ((pb / TW) * s) * IW + (pb % TW) * s;
+#pragma unroll
+        for (int tl = 0; tl < kMaxTaps; ++tl) {
+          if (tl < nt) {
+            const int t = t0 + tl;
+            const int khi = t / g.kw, kwi = t - khi * g.kw;
+            const int toff = (khi * d) * IW + kwi * d;
+            const u32x4 bf = tr_frag(halo, ha + toff, hb + toff, ci_tile * 16, lane);
+            if (wave_active) {
+#pragma unroll
+              for (int mi = 0; mi < NCO; ++mi) Mma<T>::run(acc[tl][mi], af[mi], bf);
+            }
+          }
+        }
+      } else {
+        // f32: v_mfma_f32_16x16x4_f32, one float per lane per operand: A[m = l15][k = lg], B[k = lg][n = l15]
+        const int pk = k0 + lg;
+        const int hk = ((pk / TW) * s) * IW + (pk % TW) * s;
+        float af[NCO];
+#pragma unroll
+        for (int mi = 0; mi < NCO; ++mi) {
+          const int ch = (co_tile0 + mi) * 16 + l15;
+          af[mi] = *reinterpret_cast<const float*>(ytile + lds_off(pk, ch >> 2) + ((ch & 3) << 2));
+        }
+        const int chx = ci_tile * 16 + l15;
+#pragma unroll
+        for (int tl = 0; tl < kMaxTaps; ++tl) {
+          if (tl < nt) {
+            const int t = t0 + tl;
+            const int khi = t / g.kw, kwi = t - khi * g.kw;
+            const int row = hk + (khi * d) * IW + kwi * d;
+            const float bv = *reinterpret_cast<const float*>(halo + lds_off(row, chx >> 2) + ((chx & 3) << 2));
+            if (wave_active) {
+#pragma unroll
+              for (int mi = 0; mi < NCO; ++mi)
+                acc[tl][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bv, acc[tl][mi], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- flush: f32 atomics into the packed gradient buffer [nq][T][Mpad][CK] ----
+  if (wave_active) {
+#pragma unroll
+    for (int tl = 0; tl < kMaxTaps; ++tl) {
+      if (tl < nt) {
+        float* dst = p.dwp + ((long)(q * T_ + t0 + tl) * p.Mpad) * CK;
+#pragma unroll
+        for (int mi = 0; mi < NCO; ++mi) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = m0 + (co_tile0 + mi) * 16 + 4 * lg + r;
+            if (m < p.Mpad) atomicAdd(dst + (long)m * CK + ci_tile * 16 + l15, acc[tl][mi][r]);
+          }
+        }
+      }
+    }
+  }
+  if (p.dbias && q == 0 && tgi == 0) {
+    const int ch = tid % CK;
+    if (ch < cout_m) atomicAdd(p.dbias + m0 + ch, bsum);
+  }
+}
+
+template <typename T, int TH, int TW>
+int launch(const WgArgs& a, hipStream_t s) {
+  auto kern = conv_wgrad_kernel<T, TH, TW>;
+  const ConvGeom& g = a.g;
+  const int IH = (TH - 1) * g.stride + (g.kh - 1) * g.dil + 1, IW = (TW - 1) * g.stride + (g.kw - 1) * g.dil + 1;
+  const size_t lds = (((size_t)IH * IW * 128 + 15) & ~(size_t)15) + (size_t)TH * TW * 128;
+  if (lds > 160 * 1024) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_wgrad: halo tile does not fit LDS (k=%dx%d dil=%d)", g.kh, g.kw, g.dil);
+  static size_t attr_set = 0;
+  if (lds > 64 * 1024 && attr_set == 0) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: cannot raise dynamic LDS limit");
+    attr_set = 1;
+  }
+  const int CK = 8 * Chunk<T>::N;
+  const int nmb = sdhip_cdiv(a.Cout, CK);
+  const int gy = nmb * a.nq * a.ntg;
+  const int ntiles = g.B * sdhip_cdiv(g.Ho, TH) * sdhip_cdiv(g.Wo, TW);
+  int gx = sdhip_cdiv(1024, gy);
+  if (gx > ntiles) gx = ntiles;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, s, a);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+// ---- weight (un)packing -------------------------------------------------------
+// dst[q][t][m][c] = src[m*sm + (q*CK+c)*sk + (flip ? T-1-t : t)]   (zero padded)
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int M, int Mpad, int K, int Tn,
+                            long sm, long sk, int flip, long total) {
+  constexpr int CK = 8 * Chunk<T>::N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CK);
+    long r = i / CK;
+    const int m = (int)(r % Mpad); r /= Mpad;
+    const int t = (int)(r % Tn);
+    const int q = (int)(r / Tn);
+    const int k = q * CK + c;
+    float v = 0.f;
+    if (m < M && k < K) v = src[m * sm + k * sk + (flip ? Tn - 1 - t : t)];
+    Elem<T>::st(dst + i, v);
+  }
+}
+
+// grad[m*sm + k*sk + tt] (+)= acc[q][t][m][c]
+__global__ void unpack_kernel(const float* __restrict__ acc, float* __restrict__ grad, int M, int Mpad, int K, int Tn,
+                              int CK, long sm, long sk, int flip, int accumulate, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // iterate over the destination so writes are coalesced: i = (m*K + k)*T + t for the natural (M,K,T) order
+    const int t = (int)(i % Tn);
+    long r = i / Tn;
+    const int k = (int)(r % K);
+    const int m = (int)(r / K);
+    const int tt = flip ? Tn - 1 - t : t;
+    const float v = acc[(((long)(k / CK) * Tn + tt) * Mpad + m) * CK + (k % CK)];
+    float* dst = grad + m * sm + k * sk + t;
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+
+}  // namespace
+
+extern "C" long sdhip_conv_packed_elems(int M, int K, int T, int dtype) {
+  const int ck = conv_ck(dtype);
+  return (long)((K + ck - 1) / ck) * T * ((M + 15) & ~15) * ck;
+}
+
+extern "C" int sdhip_conv_pack_weights(const float* src, void* dst, int M, int K, int T,
+                                       long stride_m, long stride_k, int flip, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(src && dst && M > 0 && K > 0 && T > 0, "conv_pack_weights: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv_pack_weights: unknown dtype %d", dtype);
+  const long total = sdhip_conv_packed_elems(M, K, T, dtype);
+  const int Mpad = (M + 15) & ~15;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SDHIP_BF16)
+    hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, src, (bf16_t*)dst, M, Mpad, K, T, stride_m, stride_k, flip, total);
+  else
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, s, src, (float*)dst, M, Mpad, K, T, stride_m, stride_k, flip, total);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_conv_unpack_wgrad(const float* acc, float* grad, int M, int K, int T,
+                                       long stride_m, long stride_k, int flip, int accumulate, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(acc && grad && M > 0 && K > 0 && T > 0, "conv_unpack_wgrad: bad arguments");
+  const long total = (long)M * K * T;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, grad, M, (M + 15) & ~15, K, T,
+                     conv_ck(dtype), stride_m, stride_k, flip, accumulate, total);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* dbias,
+                                  const float* in_scale, const float* in_shift,
+                                  int B, int H, int W, int Cin, int ldx,
+                                  int Ho, int Wo, int Cout, int lddy,
+                                  int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                                  int in_relu, int groups, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(x && dy && dw_packed, "conv2d_wgrad: null pointer");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv2d_wgrad: unknown dtype %d", dtype);
+  SDHIP_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_wgrad: empty tensor");
+  SDHIP_CHECK_ARG(ldx >= Cin && lddy >= Cout, "conv2d_wgrad: pixel stride smaller than channel count");
+  SDHIP_CHECK_ARG(groups >= 1 && B % groups == 0, "conv2d_wgrad: batch %d not divisible by %d stat groups", B, groups);
+  SDHIP_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale/in_shift must come together");
+  const int V = dtype == SDHIP_BF16 ? 8 : 4, CK = 8 * V, T = kh * kw;
+  WgArgs a;
+  a.x = x; a.dy = dy; a.dwp = dw_packed; a.dbias = dbias; a.in_scale = in_scale; a.in_shift = in_shift;
+  a.g = ConvGeom{B, H, W, Ho, Wo, kh, kw, stride, dil, pad_t, pad_l};
+  a.Cin = Cin; a.ldx = ldx; a.Cout = Cout; a.Mpad = (Cout + 15) & ~15; a.lddy = lddy;
+  a.in_relu = in_relu; a.groups = groups;
+  a.nq = sdhip_cdiv(Cin, CK);
+  a.ntg = sdhip_cdiv(T, kMaxTaps);
+  a.tpb = sdhip_cdiv(T, a.ntg);  // balanced tap groups (25 -> 9,8,8)
+  a.ntg = sdhip_cdiv(T, a.tpb);
+  a.vec_x = (Cin % V == 0) && (ldx % V == 0) && (((uintptr_t)x & 15) == 0);
+  a.vec_dy = (Cout % V == 0) && (lddy % V == 0) && (((uintptr_t)dy & 15) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const long n = sdhip_conv_packed_elems(Cout, Cin, T, dtype);
+  if (hipMemsetAsync(dw_packed, 0, n * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
+  if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
+  const bool wide = Wo >= 24;
+  if (dtype == SDHIP_BF16) return wide ? launch<bf16_t, 4, 32>(a, s) : launch<bf16_t, 4, 16>(a, s);
+  return wide ? launch<float, 4, 32>(a, s) : launch<float, 4, 16>(a, s);
+}

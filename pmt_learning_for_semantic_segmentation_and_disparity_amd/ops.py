@@ -78,3 +78,289 @@ class _CorrFn(torch.autograd.Function):
 
 def correlation(in1, in2, patch_h, patch_w, dilation_patch=1):
     return _CorrFn.apply(in1, in2, patch_h, patch_w, dilation_patch)
+
+
+# ============================================================================ convolution
+import weakref
+
+_pack_cache = {}   # id(weight parameter) -> (weakref, {(mode, dtype): (version, packed)})
+
+
+def _cache_entry(weight):
+    k = id(weight)
+    hit = _pack_cache.get(k)
+    if hit is None or hit[0]() is not weight:
+        hit = (weakref.ref(weight, lambda _r, k=k: _pack_cache.pop(k, None)), {})
+        _pack_cache[k] = hit
+    return hit[1]
+
+
+def _pack_params(kind, mode, Cout, Cin, T):
+    """(M, K, stride_m, stride_k, flip) of include/sdhip.h for a Conv2d / stride-1 ConvTranspose2d weight."""
+    if kind == 'conv':       # weight (Cout, Cin, kh, kw)
+        return (Cout, Cin, Cin * T, T, 0) if mode == 'fwd' else (Cin, Cout, T, Cin * T, 1)
+    if kind == 'deconv':     # weight (Cin, Cout, kh, kw), run as a correlation with flipped taps
+        return (Cout, Cin, T, Cout * T, 1) if mode == 'fwd' else (Cin, Cout, Cout * T, T, 0)
+    raise _lib.SdhipError("unknown conv kind %r" % kind)
+
+
+def packed_weight(weight, kind, mode, dtype):
+    """Pack an f32 parameter for the kernels (cached per parameter version, repacked after each optimizer step)."""
+    Cout, Cin = (weight.shape[0], weight.shape[1]) if kind == 'conv' else (weight.shape[1], weight.shape[0])
+    T = weight.shape[2] * weight.shape[3]
+    ent = _cache_entry(weight)
+    key = (mode, dtype)
+    hit = ent.get(key)
+    if hit is not None and hit[0] == weight._version and not torch.cuda.is_current_stream_capturing():
+        return hit[1]
+    M, K, sm, sk, flip = _pack_params(kind, mode, Cout, Cin, T)
+    dt = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+    buf = torch.empty(_lib.packed_elems(M, K, T, dt), dtype=dtype, device=weight.device)
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    call("sdhip_conv_pack_weights", ptr(w), ptr(buf), M, K, T, sm, sk, flip, dt, stream_ptr())
+    ent[key] = (weight._version, buf)
+    return buf
+
+
+class ConvSpec:
+    """Geometry of one convolution in correlation form (what the kernels take)."""
+    __slots__ = ("kind", "kh", "kw", "stride", "dil", "pad_t", "pad_l", "Ho", "Wo")
+
+    def __init__(self, kind, kh, kw, stride, dil, pad_t, pad_l, Ho, Wo):
+        self.kind, self.kh, self.kw, self.stride, self.dil = kind, kh, kw, stride, dil
+        self.pad_t, self.pad_l, self.Ho, self.Wo = pad_t, pad_l, Ho, Wo
+
+
+def _conv_launch(x, ldx, wp, y, ldy, bias, in_scale, in_shift, stats, B, H, W, Cin, Ho, Wo, Cout,
+                 kh, kw, stride, dil, pad_t, pad_l, in_relu, groups, act, accumulate):
+    call("sdhip_conv2d_fwd", ptr(x), ptr(wp), ptr(y), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(stats),
+         B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, stride, dil, pad_t, pad_l,
+         int(in_relu), groups, act, int(accumulate), dtype_code(x), stream_ptr())
+
+
+class _ConvFn(torch.autograd.Function):
+    """y (, stats) = conv(pro(x)); see sdhip_conv2d_fwd in include/sdhip.h."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, in_scale, in_shift, spec, in_relu, groups, act, want_stats):
+        _require_gpu(x, weight)
+        B, Cin, H, W = x.shape
+        xv, ldx = nhwc_view(x)
+        Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
+        wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
+        y = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
+        stats = torch.zeros((groups, 2, Cout), dtype=torch.float64, device=x.device) if want_stats else None
+        b32 = bias.detach().float() if bias is not None else None
+        _conv_launch(xv, ldx, wp, y, Cout, b32, in_scale, in_shift, stats, B, H, W, Cin, spec.Ho, spec.Wo, Cout,
+                     spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, in_relu, groups, act, False)
+        ctx.spec, ctx.in_relu, ctx.groups, ctx.act, ctx.ldx = spec, in_relu, groups, act, ldx
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(xv, weight, in_scale, in_shift, y if (want_stats or act) else None)
+        if want_stats:
+            return y, stats
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, gstats=None):
+        xv, weight, in_scale, in_shift, ysaved = ctx.saved_tensors
+        spec, groups, act, ldx = ctx.spec, ctx.groups, ctx.act, ctx.ldx
+        B, Cin, H, W = xv.shape
+        Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
+        dt = dtype_code(xv)
+        npix_o = B * spec.Ho * spec.Wo
+        g, ldg = nhwc_view(gy)
+        if gstats is not None:      # gradient through the batch statistics of the BatchNorm that follows
+            g2 = empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
+            call("sdhip_stats_fix", ptr(g), ldg, ptr(ysaved), Cout, ptr(g2), Cout, ptr(gstats.contiguous()),
+                 npix_o, Cout, groups, dt, stream_ptr())
+            g, ldg = g2, Cout
+        if act:                     # activation fused in the epilogue: derivative from the stored output
+            g2 = empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
+            call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(ysaved), Cout, ptr(g2), Cout, None, None, None, None,
+                 npix_o, Cout, 1, 1 if act == 1 else 4, dt, stream_ptr())
+            g, ldg = g2, Cout
+        gx = gscale = gshift = gw = gb = None
+        T = spec.kh * spec.kw
+        if ctx.needs_input_grad[0]:
+            if spec.stride != 1:
+                raise _lib.SdhipError("data gradient of a strided convolution is not implemented (only image inputs feed one)")
+            wd = packed_weight(weight, spec.kind, 'dgrad', xv.dtype)
+            gpost = empty_nhwc(B, Cin, H, W, xv.dtype, xv.device)
+            pt = spec.dil * (spec.kh - 1) - spec.pad_t
+            pl = spec.dil * (spec.kw - 1) - spec.pad_l
+            _conv_launch(g, ldg, wd, gpost, Cin, None, None, None, None, B, spec.Ho, spec.Wo, Cout, H, W, Cin,
+                         spec.kh, spec.kw, 1, spec.dil, pt, pl, False, 1, 0, False)
+            if in_scale is not None:
+                gx = empty_nhwc(B, Cin, H, W, xv.dtype, xv.device)
+                gscale = torch.empty_like(in_scale)
+                gshift = torch.empty_like(in_shift)
+                call("sdhip_affine_act_bwd", ptr(gpost), Cin, ptr(xv), ldx, ptr(gx), Cin, ptr(in_scale), ptr(in_shift),
+                     ptr(gscale), ptr(gshift), B * H * W, Cin, groups, 1 if ctx.in_relu else 0, dt, stream_ptr())
+            else:
+                gx = gpost
+        elif in_scale is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
+            raise _lib.SdhipError("prologue gradients need the input gradient path")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            acc = torch.empty(_lib.packed_elems(Cout, Cin, T, dt), dtype=torch.float32, device=xv.device)
+            gb = torch.empty(Cout, dtype=torch.float32, device=xv.device) if ctx.has_bias else None
+            call("sdhip_conv2d_wgrad", ptr(xv), ptr(g), ptr(acc), ptr(gb), ptr(in_scale), ptr(in_shift),
+                 B, H, W, Cin, ldx, spec.Ho, spec.Wo, Cout, ldg, spec.kh, spec.kw, spec.stride, spec.dil,
+                 spec.pad_t, spec.pad_l, int(ctx.in_relu), groups, dt, stream_ptr())
+            gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            M, K, sm, sk, flip = _pack_params(spec.kind, 'fwd', Cout, Cin, T)
+            call("sdhip_conv_unpack_wgrad", ptr(acc), ptr(gw), M, K, T, sm, sk, flip, 0, dt, stream_ptr())
+        return gx, gw, gb, gscale, gshift, None, None, None, None, None
+
+
+def conv_same_geometry(H, W, k, stride, dil):
+    """TF-'same' padding of conv2dSame (models/torch_model.py:276-281): output ceil(size/stride), extra pad bottom/right."""
+    def one(size):
+        out = -(-size // stride)
+        total = max((out - 1) * stride - size + dil * (k - 1) + 1, 0)
+        return out, total // 2
+    Ho, pt = one(H)
+    Wo, pl = one(W)
+    return Ho, Wo, pt, pl
+
+
+def deconv_same_geometry(H, W, k, dil):
+    """Stride-1 ConvTranspose2dSame (models/torch_model.py:320-346): full transposed conv of size H+dil*(k-1),
+    cropped from start = full//2 - H//2; as a correlation with flipped taps the top/left padding is dil*(k-1) - start."""
+    D = dil * (k - 1)
+    def one(size):
+        start = (size + D) // 2 - size // 2
+        return D - start
+    return one(H), one(W)
+
+
+def conv2d(x, weight, bias=None, *, kind='conv', stride=1, dilation=1, padding=0, in_scale=None, in_shift=None,
+           in_relu=False, groups=1, act=0, want_stats=False):
+    """padding: int (symmetric, nn.Conv2d), 'same' (conv2dSame) or 'ctsame' (stride-1 ConvTranspose2dSame)."""
+    B, C, H, W = x.shape
+    kh, kw = weight.shape[2], weight.shape[3]
+    if kind == 'deconv':
+        if stride != 1 or padding != 'ctsame' or kh != kw:
+            raise _lib.SdhipError("ConvTranspose2d is implemented for stride 1 with 'same' cropping only")
+        pt, pl = deconv_same_geometry(H, W, kh, dilation)
+        Ho, Wo = H, W
+    elif padding == 'same':
+        if kh != kw:
+            raise _lib.SdhipError("'same' padding needs a square kernel")
+        Ho, Wo, pt, pl = conv_same_geometry(H, W, kh, stride, dilation)
+    else:
+        pt = pl = int(padding)
+        Ho = (H + 2 * pt - dilation * (kh - 1) - 1) // stride + 1
+        Wo = (W + 2 * pl - dilation * (kw - 1) - 1) // stride + 1
+    spec = ConvSpec(kind, kh, kw, stride, dilation, pt, pl, Ho, Wo)
+    return _ConvFn.apply(x, weight, bias, in_scale, in_shift, spec, in_relu, groups, act, want_stats)
+
+
+# ============================================================================ batch norm pieces
+class _BNFinalizeFn(torch.autograd.Function):
+    """(stats, gamma, beta) -> (scale, shift); running statistics are updated in place in training mode."""
+
+    @staticmethod
+    def forward(ctx, stats, gamma, beta, running_mean, running_var, count, eps, momentum, groups):
+        C = gamma.numel()
+        dev = gamma.device
+        scale = torch.empty((groups, C), dtype=torch.float32, device=dev)
+        shift = torch.empty((groups, C), dtype=torch.float32, device=dev)
+        mean = torch.empty((groups, C), dtype=torch.float32, device=dev)
+        invstd = torch.empty((groups, C), dtype=torch.float32, device=dev)
+        call("sdhip_bn_finalize", ptr(stats), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+             ptr(scale), ptr(shift), ptr(mean), ptr(invstd), C, groups, float(count), float(eps),
+             float(momentum), stream_ptr())
+        ctx.save_for_backward(gamma, mean, invstd)
+        ctx.cfg = (C, groups, float(count), stats is not None)
+        return scale, shift
+
+    @staticmethod
+    def backward(ctx, gscale, gshift):
+        gamma, mean, invstd = ctx.saved_tensors
+        C, groups, count, train = ctx.cfg
+        dev = gamma.device
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        dstats = torch.empty((groups, 2, C), dtype=torch.float64, device=dev) if train else None
+        call("sdhip_bn_finalize_bwd", ptr(gscale.contiguous()), ptr(gshift.contiguous()), ptr(gamma), ptr(mean), ptr(invstd),
+             ptr(dgamma), ptr(dbeta), ptr(dstats), C, groups, count, int(train), stream_ptr())
+        return dstats, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_scale_shift(bn, stats, count, groups=1):
+    """scale/shift of an nn.BatchNorm2d: from batch statistics (training; running stats updated like the
+    reference's sequential calls) or from the running statistics (eval)."""
+    if bn.training:
+        if stats is None:
+            raise _lib.SdhipError("training-mode BatchNorm needs batch statistics")
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += groups
+        return _BNFinalizeFn.apply(stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, bn.eps, mom, groups)
+    return _BNFinalizeFn.apply(None, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, bn.eps, 0.0, groups)
+
+
+class _AffineActFn(torch.autograd.Function):
+    """y = act(x*scale + shift) (+ residual)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, act, groups):
+        _require_gpu(x)
+        B, C, H, W = x.shape
+        xv, ldx = nhwc_view(x)
+        rv, ldr = nhwc_view(residual) if residual is not None else (None, 0)
+        y = empty_nhwc(B, C, H, W, x.dtype, x.device)
+        call("sdhip_affine_act", ptr(xv), ldx, ptr(y), C, ptr(rv), ldr, ptr(scale), ptr(shift), B * H * W, C, groups, act,
+             dtype_code(x), stream_ptr())
+        ctx.save_for_backward(xv, scale, shift)
+        ctx.cfg = (ldx, act, groups, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xv, scale, shift = ctx.saved_tensors
+        ldx, act, groups, has_res = ctx.cfg
+        B, C, H, W = xv.shape
+        g, ldg = nhwc_view(gy)
+        gx = empty_nhwc(B, C, H, W, xv.dtype, xv.device)
+        need = scale is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        gscale = torch.empty_like(scale) if need else None
+        gshift = torch.empty_like(shift) if need else None
+        call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(xv), ldx, ptr(gx), C, ptr(scale), ptr(shift), ptr(gscale), ptr(gshift),
+             B * H * W, C, groups, act, dtype_code(xv), stream_ptr())
+        return gx, gscale, gshift, (gy if has_res else None), None, None
+
+
+def affine_act(x, scale=None, shift=None, residual=None, act=0, groups=1):
+    return _AffineActFn.apply(x, scale, shift, residual, act, groups)
+
+
+def channel_stats(x, groups=1):
+    """Batch statistics (f64 sum, sum of squares) of a tensor no conv epilogue produced them for."""
+    return _ChannelStatsFn.apply(x, groups)
+
+
+class _ChannelStatsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, groups):
+        _require_gpu(x)
+        B, C, H, W = x.shape
+        xv, ldx = nhwc_view(x)
+        stats = torch.empty((groups, 2, C), dtype=torch.float64, device=x.device)
+        call("sdhip_channel_stats", ptr(xv), ldx, ptr(stats), B * H * W, C, groups, 1, dtype_code(x), stream_ptr())
+        ctx.save_for_backward(xv)
+        ctx.cfg = (ldx, groups)
+        return stats
+
+    @staticmethod
+    def backward(ctx, gstats):
+        (xv,) = ctx.saved_tensors
+        ldx, groups = ctx.cfg
+        B, C, H, W = xv.shape
+        zero = torch.zeros((B, H, W, C), dtype=xv.dtype, device=xv.device).permute(0, 3, 1, 2)
+        gx = empty_nhwc(B, C, H, W, xv.dtype, xv.device)
+        call("sdhip_stats_fix", ptr(zero), C, ptr(xv), ldx, ptr(gx), C, ptr(gstats.contiguous()), B * H * W, C, groups,
+             dtype_code(xv), stream_ptr())
+        return gx, None

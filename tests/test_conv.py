@@ -1,0 +1,173 @@
+"""conv2dSame / ConvTranspose2dSame / convbn / deconvbn / Conv2DownUp: HIP kernels vs the reference-captured
+golden vectors (tests/golden/ops.npz) and vs the CPU oracle on larger, ragged and bf16 cases."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_models as R
+from oracle.detweights import fill_state_dict, randn_input
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ops.npz")
+
+CONV_CASES = [("c1", 8, 16, 1, 1, 1, 9, 11), ("c3", 16, 8, 3, 1, 1, 12, 17), ("c5", 8, 8, 5, 1, 1, 13, 16),
+              ("c7s2", 3, 8, 7, 2, 1, 17, 20), ("c5d2", 3, 1, 5, 1, 2, 16, 19), ("c3s2", 8, 8, 3, 2, 1, 15, 16)]
+DECONV_CASES = [("d3", 8, 16, 3, 1, 12, 17), ("d5", 8, 4, 5, 1, 13, 16)]
+
+
+def _close(got, want, tol, what=""):
+    got = got.detach().float().cpu()
+    want = torch.as_tensor(want).float()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, "%s: max err %.3e > %.1e * %.3g" % (what, err, tol, scale)
+
+
+# ------------------------------------------------------------------ CPU: the oracle reproduces the golden vectors
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_oracle_conv_matches_golden(case):
+    name, ci, co, k, s, d, H, W = case
+    gold = np.load(GOLD)
+    m = fill_state_dict(R.conv2dSame(ci, co, k, s, 'same', d, bias=True), 11)
+    x = randn_input(11, name, (2, ci, H, W)).requires_grad_(True)
+    y = m(x)
+    y.backward(randn_input(12, name, tuple(y.shape)))
+    np.testing.assert_allclose(y.detach().numpy(), gold["conv.%s.y" % name], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), gold["conv.%s.gx" % name], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(m.c2d.weight.grad.numpy(), gold["conv.%s.gw" % name], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,ctor,shape", [
+    ("convbn", lambda: R.convbn(8, 16, 3, 1, 'same', 1), (4, 8, 10, 12)),
+    ("deconvbn", lambda: R.deconvbn(8, 8, 5, 1, 'same', 1), (4, 8, 10, 12)),
+    ("cdu_last", lambda: R.Conv2DownUp(8, 16, 3, True), (2, 8, 12, 16)),
+    ("cdu_nolast", lambda: R.Conv2DownUp(16, 8, 5, False), (2, 16, 12, 16))])
+def test_oracle_blocks_match_golden(name, ctor, shape):
+    gold = np.load(GOLD)
+    m = fill_state_dict(ctor(), 15).train()
+    x = randn_input(15, name, shape).requires_grad_(True)
+    y = m(x)
+    y.backward(randn_input(16, name, tuple(y.shape)))
+    np.testing.assert_allclose(y.detach().numpy(), gold["%s.y" % name], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(x.grad.numpy(), gold["%s.gx" % name], rtol=1e-3, atol=1e-4)
+    for k, v in m.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            np.testing.assert_allclose(v.numpy(), gold["%s.state.%s" % (name, k)], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ GPU: HIP path vs golden / oracle
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_hip_conv_matches_golden(case):
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    name, ci, co, k, s, d, H, W = case
+    gold = np.load(GOLD)
+    m = fill_state_dict(N.conv2dSame(ci, co, k, s, 'same', d, bias=True), 11).cuda()
+    x = randn_input(11, name, (2, ci, H, W)).cuda().requires_grad_(s == 1)
+    y = m(x)
+    _close(y, gold["conv.%s.y" % name], 1e-4, name + ".y")
+    y.backward(randn_input(12, name, tuple(y.shape)).cuda())
+    if s == 1:
+        _close(x.grad, gold["conv.%s.gx" % name], 1e-4, name + ".gx")
+    _close(m.c2d.weight.grad, gold["conv.%s.gw" % name], 1e-4, name + ".gw")
+    _close(m.c2d.bias.grad, gold["conv.%s.gb" % name], 1e-4, name + ".gb")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", DECONV_CASES)
+def test_hip_deconv_matches_golden(case):
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    name, ci, co, k, s, H, W = case
+    gold = np.load(GOLD)
+    m = fill_state_dict(N.ConvTranspose2dSame(ci, co, k, s, 'same', 1, bias=True), 13).cuda()
+    x = randn_input(13, name, (2, ci, H, W)).cuda().requires_grad_(True)
+    y = m(x)
+    _close(y, gold["deconv.%s.y" % name], 1e-4, name + ".y")
+    y.backward(randn_input(14, name, tuple(y.shape)).cuda())
+    _close(x.grad, gold["deconv.%s.gx" % name], 1e-4, name + ".gx")
+    _close(m.ct2d.weight.grad, gold["deconv.%s.gw" % name], 1e-4, name + ".gw")
+    _close(m.ct2d.bias.grad, gold["deconv.%s.gb" % name], 1e-4, name + ".gb")
+
+
+@pytest.mark.gpu
+def test_hip_strided_deconv_is_refused():
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    m = N.ConvTranspose2dSame(8, 8, 3, 2, 'same', 1).cuda()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 8, 4, 4, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,ctor,shape", [
+    ("convbn", lambda N: N.convbn(8, 16, 3, 1, 'same', 1), (4, 8, 10, 12)),
+    ("deconvbn", lambda N: N.deconvbn(8, 8, 5, 1, 'same', 1), (4, 8, 10, 12)),
+    ("cdu_last", lambda N: N.Conv2DownUp(8, 16, 3, True), (2, 8, 12, 16)),
+    ("cdu_nolast", lambda N: N.Conv2DownUp(16, 8, 5, False), (2, 16, 12, 16))])
+def test_hip_blocks_match_golden(name, ctor, shape):
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    gold = np.load(GOLD)
+    m = fill_state_dict(ctor(N), 15).cuda().train()
+    x = randn_input(15, name, shape).cuda().requires_grad_(True)
+    y = m(x)
+    _close(y, gold["%s.y" % name], 2e-4, name + ".y")
+    y.backward(randn_input(16, name, tuple(y.shape)).cuda())
+    _close(x.grad, gold["%s.gx" % name], 1e-3, name + ".gx")
+    for k, v in m.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            _close(v, gold["%s.state.%s" % (name, k)], 1e-4, name + "." + k)
+    for k, p in m.named_parameters():
+        gk = "%s.grad.%s" % (name, k)
+        if gk in gold.files:
+            _close(p.grad, gold[gk], 1e-3, gk)
+
+
+BIG = [  # name, cin, cout, k, dil, kind, H, W, B
+    ("k5_64", 64, 64, 5, 1, 'conv', 40, 70, 2),       # the hot shape (Conv2DownUp5), ragged tiles
+    ("k3_128_64", 128, 64, 3, 1, 'conv', 33, 47, 2),  # two channel chunks
+    ("k1_65_64", 65, 64, 1, 1, 'conv', 24, 40, 2),    # ragged Cin (scalar staging path)
+    ("k1_2048_64", 2048, 64, 1, 1, 'conv', 8, 16, 2),
+    ("k3_32_2", 32, 2, 3, 1, 'deconv', 32, 48, 2),    # segmentation head, Cout = labels
+    ("k5_64_1", 64, 1, 5, 1, 'deconv', 32, 48, 2),    # disparity head, Cout = 1
+    ("k3_d6", 32, 48, 3, 6, 'conv', 20, 36, 2),       # ASPP-style dilation (plain padding = dilation)
+    ("k3_32_32", 32, 32, 3, 1, 'deconv', 64, 128, 4),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("case", BIG)
+def test_hip_conv_matches_oracle(case, dtype, tol):
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    name, ci, co, k, dil, kind, H, W, B = case
+    if kind == 'conv':
+        ref = R.conv2dSame(ci, co, k, 1, 'same', dil, bias=True)
+        mine = N.conv2dSame(ci, co, k, 1, 'same', dil, bias=True)
+    else:
+        ref = R.ConvTranspose2dSame(ci, co, k, 1, 'same', 1, bias=True)
+        mine = N.ConvTranspose2dSame(ci, co, k, 1, 'same', 1, bias=True)
+    fill_state_dict(ref, 41)
+    mine.load_state_dict(ref.state_dict())
+    x = randn_input(41, name, (B, ci, H, W))
+    g = randn_input(42, name, (B, co, H, W))
+    if dtype == torch.bfloat16:  # same rounded operands on both sides; weights rounded like the kernel does
+        x = x.bfloat16().float(); g = g.bfloat16().float()
+        with torch.no_grad():
+            for p in ref.parameters():
+                if p.dim() > 1:
+                    p.copy_(p.bfloat16().float())
+        mine.load_state_dict(ref.state_dict())
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g)
+    mine = mine.cuda()
+    xd = x.cuda().to(dtype).requires_grad_(True)
+    y = mine(xd)
+    assert y.dtype == dtype and y.shape == yr.shape
+    y.backward(g.cuda().to(dtype))
+    _close(y, yr.detach(), tol, name + ".y")
+    _close(xd.grad, xr.grad, tol, name + ".gx")
+    rp = dict(ref.named_parameters())
+    for kname, p in mine.named_parameters():
+        _close(p.grad, rp[kname].grad, tol, name + "." + kname)

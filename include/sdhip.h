@@ -97,13 +97,15 @@ int sdhip_conv_unpack_wgrad(const float* acc, float* grad, int M, int K, int T,
  *   pro(x) = x, or relu?(x*in_scale[g][k] + in_shift[g][k]) when in_scale != NULL (the BatchNorm+ReLU
  *            that precedes the conv, models/densenet.py:41-45,75-93); zero padding is applied AFTER pro;
  *   g      = b / (B/groups): statistics group of image b (left/right tower passes share a launch);
- *   stats  : if non-NULL, f64 [groups][2][Cout]; the kernel ADDS sum(y) and sum(y^2) over pixels
+ *   stats  : if non-NULL, f64 [groups][2][stats_ld >= Cout] (stats_ld <= 0 means Cout; a slice of a wider
+ *            statistics slab is addressed by offsetting the pointer); the kernel ADDS sum(y) and sum(y^2) over pixels
  *            (of the stored, rounded values) — the batch statistics of the BatchNorm that follows;
  *   act    : 0 none, 1 ReLU, 2 sigmoid;  accumulate != 0: y += result.
  * (pad_t, pad_l) is the top/left padding; bottom/right padding is implied by (Ho, Wo)
  * (TF-"same" padding of models/torch_model.py:276-281 is asymmetric for stride 2). */
 int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
-                     const float* bias, const float* in_scale, const float* in_shift, double* stats,
+                     const float* bias, const float* in_scale, const float* in_shift,
+                     double* stats, int stats_ld,
                      int B, int H, int W, int Cin, int ldx,
                      int Ho, int Wo, int Cout, int ldy,
                      int kh, int kw, int stride, int dil, int pad_t, int pad_l,
@@ -123,35 +125,66 @@ int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* d
  * Replaces nn.BatchNorm2d as used at models/dsnet_t2.py:16-117,
  * models/densenet.py:25-128, models/aspp.py:7-32; statistics semantics as in
  * sync_batchnorm/batchnorm.py:114-126.  Tensors are [npix][C] row views with a
- * pixel stride; rows of statistics group g are the g-th npix/groups rows.
+ * pixel stride; rows of statistics group g are the g-th npix/groups rows.  Statistics tensors are
+ * f64 [groups][2][stats_ld] (stats_ld <= 0: = C), so a channel slice of a wider slab can be addressed.
  * ------------------------------------------------------------------------- */
 /* stats[g][0][c] += sum x, stats[g][1][c] += sum x^2 (f64). */
-int sdhip_channel_stats(const void* x, int ldx, double* stats, long npix, int C, int groups,
+int sdhip_channel_stats(const void* x, int ldx, double* stats, int stats_ld, long npix, int C, int groups,
                         int zero_first, int dtype, void* stream);
 /* Train (stats != NULL): mean = S1/count, var = S2/count - mean^2 (biased), scale = gamma*invstd,
  * shift = beta - mean*scale; running_mean/var updated in place group by group with `momentum`
  * (running_var unbiased).  Eval (stats == NULL): scale/shift from the running statistics. */
-int sdhip_bn_finalize(const double* stats, const float* gamma, const float* beta,
+int sdhip_bn_finalize(const double* stats, int stats_ld, const float* gamma, const float* beta,
                       float* running_mean, float* running_var,
                       float* scale, float* shift, float* mean_out, float* invstd_out,
                       int C, int groups, double count, float eps, float momentum, void* stream);
 /* (dscale,dshift)[g][c] -> dgamma[c], dbeta[c] and dstats[g][2][c] (gradient w.r.t. S1, S2; zero in eval). */
 int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gamma,
                           const float* mean, const float* invstd,
-                          float* dgamma, float* dbeta, double* dstats,
+                          float* dgamma, float* dbeta, double* dstats, int stats_ld, int accumulate_dstats,
                           int C, int groups, double count, int train, void* stream);
 /* y = act(x*scale[g][c] + shift[g][c]) (+ res). scale/shift may be NULL (identity). */
 int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const void* res, int ldr,
                      const float* scale, const float* shift, long npix, int C, int groups, int act,
                      int dtype, void* stream);
 /* act: 0 none, 1 ReLU, 2 sigmoid, 4 sigmoid with x holding the sigmoid OUTPUT.
- * gx = gy*act'*scale (if gx != NULL); dscale = sum gy*act'*x, dshift = sum gy*act' (if non-NULL; zeroed here). */
+ * gx (+)= gy*act'*scale (if gx != NULL; += when accumulate != 0); dscale = sum gy*act'*x, dshift = sum gy*act' (if non-NULL; zeroed here). */
 int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
                          const float* scale, const float* shift, float* dscale, float* dshift,
-                         long npix, int C, int groups, int act, int dtype, void* stream);
+                         long npix, int C, int groups, int act, int accumulate, int dtype, void* stream);
 /* gout = gin + dstats[g][0][c] + 2*x*dstats[g][1][c]: the gradient that flows through the batch statistics. */
 int sdhip_stats_fix(const void* gin, int ldgi, const void* x, int ldx, void* gout, int ldgo,
-                    const double* dstats, long npix, int C, int groups, int dtype, void* stream);
+                    const double* dstats, int stats_ld, long npix, int C, int groups, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Pooling / resizing / broadcast product on NHWC tensors (HBM bound).
+ * Replace nn.MaxPool2d(3,2,1) (models/densenet.py:158), F.avg_pool2d / nn.AvgPool2d(p,p)
+ * (models/densenet.py:232; models/dsnet_t2.py:1983-2022), F.interpolate nearest / bilinear
+ * (models/dsnet_t2.py:927-936,1204-1275,2037-2081; models/aspp.py:88) and the attention
+ * product s2_d*at_s (models/dsnet_t2.py:1258).  Index maths follow ATen's CPU kernels.
+ * ------------------------------------------------------------------------- */
+/* 3x3 / stride 2 / pad 1 max pool; idx (u8, [B*Ho*Wo][C]) records the winning tap (first max wins). */
+int sdhip_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, unsigned char* idx,
+                         int B, int H, int W, int C, int dtype, void* stream);
+int sdhip_maxpool3s2_bwd(const void* gy, int ldg, const unsigned char* idx, void* gx, int ldgx,
+                         int B, int H, int W, int C, int dtype, void* stream);
+/* k x k / stride k average pool, no padding, floor mode (output H/k x W/k). */
+int sdhip_avgpool_fwd(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, int k,
+                      int dtype, void* stream);
+int sdhip_avgpool_bwd(const void* gy, int ldg, void* gx, int ldgx, int B, int H, int W, int C, int k,
+                      int dtype, void* stream);
+/* mode 0 nearest, 1 bilinear align_corners=False, 2 bilinear align_corners=True.
+ * scale_h/scale_w > 0 override in/out (F.interpolate(scale_factor=f) uses 1/f). */
+int sdhip_resize_fwd(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, int Ho, int Wo,
+                     int mode, float scale_h, float scale_w, int dtype, void* stream);
+/* tmp: caller-provided f32 workspace of B*Ho*W*C elements. */
+int sdhip_resize_bwd(const void* gy, int ldg, void* gx, int ldgx, float* tmp, int B, int H, int W, int C,
+                     int Ho, int Wo, int mode, float scale_h, float scale_w, int dtype, void* stream);
+/* y[p,c] = a[p,c] * m[p] and its gradients (ga = g*m, gm[p] = sum_c g*a). */
+int sdhip_mul_bcast_fwd(const void* a, int lda, const void* m, int ldm, void* y, int ldy, long npix, int C,
+                        int dtype, void* stream);
+int sdhip_mul_bcast_bwd(const void* g, int ldg, const void* a, int lda, const void* m, int ldm,
+                        void* ga, int ldga, void* gm, int ldgm, long npix, int C, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

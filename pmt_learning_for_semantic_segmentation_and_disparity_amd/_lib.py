@@ -38,14 +38,22 @@ SIGNATURES = {
     "sdhip_corr_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_conv_pack_weights": [_p, _p, _i, _i, _i, _l, _l, _i, _i, _p],
     "sdhip_conv_unpack_wgrad": [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p],
-    "sdhip_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 20 + [_p],
+    "sdhip_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 21 + [_p],
     "sdhip_conv2d_wgrad": [_p, _p, _p, _p, _p, _p] + [_i] * 18 + [_p],
-    "sdhip_channel_stats": [_p, _i, _p, _l, _i, _i, _i, _i, _p],
-    "sdhip_bn_finalize": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _d, _f, _f, _p],
-    "sdhip_bn_finalize_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _d, _i, _p],
+    "sdhip_channel_stats": [_p, _i, _p, _i, _l, _i, _i, _i, _i, _p],
+    "sdhip_bn_finalize": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _d, _f, _f, _p],
+    "sdhip_bn_finalize_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _i, _p],
     "sdhip_affine_act": [_p, _i, _p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _i, _p],
-    "sdhip_affine_act_bwd": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p],
-    "sdhip_stats_fix": [_p, _i, _p, _i, _p, _i, _p, _l, _i, _i, _i, _p],
+    "sdhip_affine_act_bwd": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p],
+    "sdhip_maxpool3s2_fwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "sdhip_maxpool3s2_bwd": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_avgpool_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_avgpool_bwd": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_resize_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p],
+    "sdhip_resize_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p],
+    "sdhip_mul_bcast_fwd": [_p, _i, _p, _i, _p, _i, _l, _i, _i, _p],
+    "sdhip_mul_bcast_bwd": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _i, _p],
+    "sdhip_stats_fix": [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _i, _i, _p],
 }
 _lib.sdhip_conv_packed_elems.argtypes = [_i, _i, _i, _i]
 _lib.sdhip_conv_packed_elems.restype = _l

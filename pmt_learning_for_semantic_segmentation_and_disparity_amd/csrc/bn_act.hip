@@ -34,18 +34,6 @@ inline RowGeom row_geom(int units) {
   return r;
 }
 
-template <typename T, bool VEC> struct Unit {
-  static constexpr int N = VEC ? Chunk<T>::N : 1;
-  static __device__ __forceinline__ void load(const T* p, float* f) {
-    if constexpr (VEC) Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(p), f);
-    else f[0] = Elem<T>::ld(p);
-  }
-  static __device__ __forceinline__ void store(T* p, const float* f) {
-    if constexpr (VEC) *reinterpret_cast<u32x4*>(p) = Chunk<T>::pack(f);
-    else Elem<T>::st(p, f[0]);
-  }
-};
-
 // y = act(x*scale + shift) (+ res);  grid: (pixel slabs, unit groups, stat groups)
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
@@ -80,11 +68,11 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
 // gx = gy * act'(x*scale+shift) * scale;  dscale += sum gy*act'*x;  dshift += sum gy*act'
 // mode 0: both; mode 1: only the reductions (gx not written)
 template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* __restrict__ gy, int ldg, const T* __restrict__ x, int ldx,
-                                                             T* __restrict__ gx, int ldgx,
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* gy, int ldg, const T* __restrict__ x, int ldx,
+                                                             T* gx, int ldgx,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              float* __restrict__ dscale, float* __restrict__ dshift,
-                                                             int C, long npix_g, int act, RowGeom rg) {
+                                                             int C, long npix_g, int act, int accumulate, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
   __shared__ float red[2][256 * (VEC ? Chunk<T>::N : 1)];
   const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
@@ -115,7 +103,15 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* __restrict
         a2[e] += gm;
         gv[e] = gm * sc[e];
       }
-      if (gx) Unit<T, VEC>::store(gx + (base + pix) * ldgx + c0, gv);
+      if (gx) {
+        if (accumulate) {
+          float old[N];
+          Unit<T, VEC>::load(gx + (base + pix) * ldgx + c0, old);
+#pragma unroll
+          for (int e = 0; e < N; ++e) gv[e] += old[e];
+        }
+        Unit<T, VEC>::store(gx + (base + pix) * ldgx + c0, gv);
+      }
     }
   }
   if (!dscale) return;  // uniform
@@ -136,8 +132,8 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* __restrict
 
 // g_out = g_in + dS1 + 2 * x * dS2   (dS is [G][2][C], f64 like the statistics it is the gradient of)
 template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void stats_fix_kernel(const T* __restrict__ gin, int ldgi, const T* __restrict__ x, int ldx,
-                                                        T* __restrict__ gout, int ldgo, const double* __restrict__ dS,
+__global__ __launch_bounds__(256) void stats_fix_kernel(const T* gin, int ldgi, const T* __restrict__ x, int ldx,
+                                                        T* gout, int ldgo, const double* __restrict__ dS, int ldc,
                                                         int C, long npix_g, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
   const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
@@ -146,7 +142,7 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const T* __restrict__ gi
   const int g = blockIdx.z, c0 = u * N;
   float a[N], b2[N];
 #pragma unroll
-  for (int e = 0; e < N; ++e) { a[e] = (float)dS[((long)g * 2 + 0) * C + c0 + e]; b2[e] = (float)(2.0 * dS[((long)g * 2 + 1) * C + c0 + e]); }
+  for (int e = 0; e < N; ++e) { a[e] = (float)dS[((long)g * 2 + 0) * ldc + c0 + e]; b2[e] = (float)(2.0 * dS[((long)g * 2 + 1) * ldc + c0 + e]); }
   const long base = (long)g * npix_g;
   for (long pix = (long)blockIdx.x * rg.ty + ty; pix < npix_g; pix += (long)gridDim.x * rg.ty) {
     float gv[N], xv[N];
@@ -160,7 +156,7 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const T* __restrict__ gi
 
 // S[g][0][c] += sum x, S[g][1][c] += sum x^2  (f64 atomics)
 template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, int ldx, double* __restrict__ S,
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, int ldx, double* __restrict__ S, int ldc,
                                                             int C, long npix_g, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
   __shared__ float red[2][256 * (VEC ? Chunk<T>::N : 1)];
@@ -188,15 +184,15 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
     for (int e = 0; e < N; ++e) {
       double s1 = 0., s2 = 0.;
       for (int r = 0; r < rg.ty; ++r) { s1 += red[0][(r * rg.tx + tx) * N + e]; s2 += red[1][(r * rg.tx + tx) * N + e]; }
-      atomicAdd(S + ((long)g * 2 + 0) * C + c0 + e, s1);
-      atomicAdd(S + ((long)g * 2 + 1) * C + c0 + e, s2);
+      atomicAdd(S + ((long)g * 2 + 0) * ldc + c0 + e, s1);
+      atomicAdd(S + ((long)g * 2 + 1) * ldc + c0 + e, s2);
     }
   }
 }
 
 // ---- per-channel finalize (tiny) ------------------------------------------------
 // train: S -> mean, invstd, scale, shift, running stats (groups applied in order)
-__global__ void bn_finalize_kernel(const double* __restrict__ S, const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ void bn_finalize_kernel(const double* __restrict__ S, int ldc, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rmean, float* __restrict__ rvar,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, int C, int G, double count, float eps, float momentum) {
@@ -214,8 +210,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ S, const float* __
   }
   float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
   for (int g = 0; g < G; ++g) {
-    const double mu = S[((long)g * 2 + 0) * C + c] / count;
-    double var = S[((long)g * 2 + 1) * C + c] / count - mu * mu;
+    const double mu = S[((long)g * 2 + 0) * ldc + c] / count;
+    double var = S[((long)g * 2 + 1) * ldc + c] / count - mu * mu;
     if (var < 0.) var = 0.;
     const float inv = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gm * inv;
@@ -233,7 +229,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ S, const float* __
 // (dscale, dshift)[G][C] -> dgamma[C], dbeta[C] (summed over groups), dS[G][2][C]
 __global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
                                        const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, double* __restrict__ dS,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, double* __restrict__ dS, int ldc, int acc_ds,
                                        int C, int G, double count, int train) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -250,11 +246,13 @@ __global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const f
         const double dinv = (double)gm * t;
         const double dvar = -0.5 * dinv * (double)inv * inv * inv;
         const double dmu = -(double)gm * inv * dh - 2.0 * mu * dvar;
-        dS[((long)g * 2 + 0) * C + c] = dmu / count;
-        dS[((long)g * 2 + 1) * C + c] = dvar / count;
-      } else {
-        dS[((long)g * 2 + 0) * C + c] = 0.;
-        dS[((long)g * 2 + 1) * C + c] = 0.;
+        double* d0 = dS + ((long)g * 2 + 0) * ldc + c;
+        double* d1 = dS + ((long)g * 2 + 1) * ldc + c;
+        *d0 = (acc_ds ? *d0 : 0.) + dmu / count;
+        *d1 = (acc_ds ? *d1 : 0.) + dvar / count;
+      } else if (!acc_ds) {
+        dS[((long)g * 2 + 0) * ldc + c] = 0.;
+        dS[((long)g * 2 + 1) * ldc + c] = 0.;
       }
     }
   }
@@ -318,7 +316,7 @@ extern "C" int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const 
 
 extern "C" int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
                                     const float* scale, const float* shift, float* dscale, float* dshift,
-                                    long npix, int C, int groups, int act, int dtype, void* stream) {
+                                    long npix, int C, int groups, int act, int accumulate, int dtype, void* stream) {
   const int G = groups;
   if (int rc = check_rows("affine_act_bwd", npix, C, G, dtype)) return rc;
   SDHIP_CHECK_ARG(gy && x && ldg >= C && ldx >= C && (!gx || ldgx >= C), "affine_act_bwd: bad pointers/strides");
@@ -329,7 +327,7 @@ extern "C" int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int 
         hipMemsetAsync(dshift, 0, sizeof(float) * (size_t)G * C, s) != hipSuccess)
       SDHIP_FAIL(SDHIP_ERR_LAUNCH, "affine_act_bwd: memset failed");
   }
-#define ARGS(T) (const T*)gy, ldg, (const T*)x, ldx, (T*)gx, ldgx, scale, shift, dscale, dshift, C, npix / G, act
+#define ARGS(T) (const T*)gy, ldg, (const T*)x, ldx, (T*)gx, ldgx, scale, shift, dscale, dshift, C, npix / G, act, accumulate
   if (dtype == SDHIP_F32) {
     const bool v = vec_rows<float>(C, {ldg, ldx, gx ? ldgx : 0}, {gy, x, gx});
     Plan pl = plan(v ? C / 4 : C, npix / G, G);
@@ -347,12 +345,13 @@ extern "C" int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int 
 }
 
 extern "C" int sdhip_stats_fix(const void* gin, int ldgi, const void* x, int ldx, void* gout, int ldgo,
-                               const double* dS, long npix, int C, int groups, int dtype, void* stream) {
+                               const double* dS, int ldc, long npix, int C, int groups, int dtype, void* stream) {
+  if (ldc <= 0) ldc = C;
   const int G = groups;
   if (int rc = check_rows("stats_fix", npix, C, G, dtype)) return rc;
   SDHIP_CHECK_ARG(gin && x && gout && dS && ldgi >= C && ldx >= C && ldgo >= C, "stats_fix: bad pointers/strides");
   hipStream_t s = (hipStream_t)stream;
-#define ARGS(T) (const T*)gin, ldgi, (const T*)x, ldx, (T*)gout, ldgo, dS, C, npix / G
+#define ARGS(T) (const T*)gin, ldgi, (const T*)x, ldx, (T*)gout, ldgo, dS, ldc, C, npix / G
   if (dtype == SDHIP_F32) {
     const bool v = vec_rows<float>(C, {ldgi, ldx, ldgo}, {gin, x, gout});
     Plan pl = plan(v ? C / 4 : C, npix / G, G);
@@ -369,15 +368,18 @@ extern "C" int sdhip_stats_fix(const void* gin, int ldgi, const void* x, int ldx
   return SDHIP_OK;
 }
 
-extern "C" int sdhip_channel_stats(const void* x, int ldx, double* stats, long npix, int C, int groups,
+extern "C" int sdhip_channel_stats(const void* x, int ldx, double* stats, int ldc, long npix, int C, int groups,
                                    int zero_first, int dtype, void* stream) {
+  if (ldc <= 0) ldc = C;
   const int G = groups;
   if (int rc = check_rows("channel_stats", npix, C, G, dtype)) return rc;
   SDHIP_CHECK_ARG(x && stats && ldx >= C, "channel_stats: bad pointers/strides");
   hipStream_t s = (hipStream_t)stream;
-  if (zero_first && hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)G * C, s) != hipSuccess)
-    SDHIP_FAIL(SDHIP_ERR_LAUNCH, "channel_stats: memset failed");
-#define ARGS(T) (const T*)x, ldx, stats, C, npix / G
+  if (zero_first) {
+    if (hipMemset2DAsync(stats, sizeof(double) * (size_t)ldc, 0, sizeof(double) * (size_t)C, 2 * (size_t)G, s) != hipSuccess)
+      SDHIP_FAIL(SDHIP_ERR_LAUNCH, "channel_stats: memset failed");
+  }
+#define ARGS(T) (const T*)x, ldx, stats, ldc, C, npix / G
   if (dtype == SDHIP_F32) {
     const bool v = vec_rows<float>(C, {ldx}, {x});
     Plan pl = plan(v ? C / 4 : C, npix / G, G);
@@ -394,14 +396,14 @@ extern "C" int sdhip_channel_stats(const void* x, int ldx, double* stats, long n
   return SDHIP_OK;
 }
 
-extern "C" int sdhip_bn_finalize(const double* stats, const float* gamma, const float* beta,
+extern "C" int sdhip_bn_finalize(const double* stats, int ldc, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var,
                                  float* scale, float* shift, float* mean_out, float* invstd_out,
                                  int C, int groups, double count, float eps, float momentum, void* stream) {
   SDHIP_CHECK_ARG(C > 0 && groups >= 1 && scale && shift, "bn_finalize: bad arguments");
   SDHIP_CHECK_ARG(stats || (running_mean && running_var), "bn_finalize: eval mode needs running statistics");
   SDHIP_CHECK_ARG(!stats || (mean_out && invstd_out && count >= 1.), "bn_finalize: train mode needs mean/invstd outputs and a count");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sdhip_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sdhip_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, ldc > 0 ? ldc : C, gamma, beta,
                      running_mean, running_var, scale, shift, mean_out, invstd_out, C, groups, count, eps, momentum);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
@@ -409,11 +411,11 @@ extern "C" int sdhip_bn_finalize(const double* stats, const float* gamma, const 
 
 extern "C" int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gamma,
                                      const float* mean, const float* invstd,
-                                     float* dgamma, float* dbeta, double* dstats,
+                                     float* dgamma, float* dbeta, double* dstats, int ldc, int accumulate_dstats,
                                      int C, int groups, double count, int train, void* stream) {
   SDHIP_CHECK_ARG(C > 0 && groups >= 1 && dscale && dshift && mean && invstd, "bn_finalize_bwd: bad arguments");
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(sdhip_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, dscale, dshift,
-                     gamma, mean, invstd, dgamma, dbeta, dstats, C, groups, count, train);
+                     gamma, mean, invstd, dgamma, dbeta, dstats, ldc > 0 ? ldc : C, accumulate_dstats, C, groups, count, train);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }

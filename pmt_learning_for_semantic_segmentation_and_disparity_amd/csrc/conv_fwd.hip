@@ -24,7 +24,7 @@ struct FwdArgs {
   ConvGeom g;
   int Cin, ldx, Cout, Mpad, ldy;
   int in_relu, groups, act, accumulate;
-  int tg, vec_in, vec_out;
+  int tg, vec_in, vec_out, stats_ld;
 };
 
 template <typename T, int TH, int TW, int BN>
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
       if (n0 + m < p.Cout) {
         const float tot = red[(0 * 2 + which) * BN + m] + red[(1 * 2 + which) * BN + m] +
                           red[(2 * 2 + which) * BN + m] + red[(3 * 2 + which) * BN + m];
-        atomicAdd(p.stats + ((long)grp * 2 + which) * p.Cout + n0 + m, (double)tot);
+        atomicAdd(p.stats + ((long)grp * 2 + which) * p.stats_ld + n0 + m, (double)tot);
       }
     }
   }
@@ -278,7 +278,8 @@ size_t lds_need(const ConvGeom& g, int th, int tw, int rows_per_tap, int tg) {
 }  // namespace
 
 extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
-                                const float* bias, const float* in_scale, const float* in_shift, double* stats,
+                                const float* bias, const float* in_scale, const float* in_shift,
+                                double* stats, int stats_ld,
                                 int B, int H, int W, int Cin, int ldx,
                                 int Ho, int Wo, int Cout, int ldy,
                                 int kh, int kw, int stride, int dil, int pad_t, int pad_l,
@@ -299,6 +300,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   a.g = ConvGeom{B, H, W, Ho, Wo, kh, kw, stride, dil, pad_t, pad_l};
   a.Cin = Cin; a.ldx = ldx; a.Cout = Cout; a.Mpad = (Cout + 15) & ~15; a.ldy = ldy;
   a.in_relu = in_relu; a.groups = groups; a.act = act; a.accumulate = accumulate;
+  a.stats_ld = stats_ld > 0 ? stats_ld : Cout;
   a.vec_in = (Cin % V == 0) && (ldx % V == 0) && (((uintptr_t)x & 15) == 0);
   a.vec_out = (ldy % 4 == 0) && (((uintptr_t)y % (4 * es)) == 0);
   const int bn = a.Mpad > 64 ? 128 : (a.Mpad > 32 ? 64 : (a.Mpad > 16 ? 32 : 16));

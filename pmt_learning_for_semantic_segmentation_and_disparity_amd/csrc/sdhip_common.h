@@ -92,4 +92,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// one "unit" of a row-wise elementwise kernel: a 16-byte chunk (VEC) or a single element
+template <typename T, bool VEC> struct Unit {
+  static constexpr int N = VEC ? Chunk<T>::N : 1;
+  static __device__ __forceinline__ void load(const T* p, float* f) {
+    if constexpr (VEC) Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(p), f);
+    else f[0] = Elem<T>::ld(p);
+  }
+  static __device__ __forceinline__ void store(T* p, const float* f) {
+    if constexpr (VEC) *reinterpret_cast<u32x4*>(p) = Chunk<T>::pack(f);
+    else Elem<T>::st(p, f[0]);
+  }
+};
+
 static inline int sdhip_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

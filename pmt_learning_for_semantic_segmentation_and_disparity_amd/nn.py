@@ -161,3 +161,207 @@ class Conv2DownUp(nn.Module):
         x = run_act_block(self.d3, x, residual=x2, groups=groups)
         x = run_act_block(self.d4, x, residual=x1, groups=groups)
         return run_act_block(self.d5, x, groups=groups) if self.lastLayer else x
+
+
+# --------------------------------------------------------------------------- pyramids, heads, full network
+from .densenet import densenet121  # noqa: E402
+
+
+def _pool_branch(p, cin):
+    return nn.Sequential(nn.AvgPool2d(p, p), convbn(cin, 32, 3, 1, 'same', 1), nn.ReLU(inplace=True))
+
+
+def _pyramid(branches, x, groups):
+    """cat([x] + [bilinear_up(relu(bn(conv3x3(avgpool_p(x))))) for each branch]) (models/dsnet_t2.py:2037-2081).
+    The pools share work: pool_2p = 2x2 pool of pool_p (identical windows, mean of equal-size means)."""
+    order = sorted(range(len(branches)), key=lambda j: branches[j][0].kernel_size)
+    outs, pooled, prev_p = [None] * len(branches), x, 1
+    for j in order:
+        p = branches[j][0].kernel_size
+        p = p if isinstance(p, int) else p[0]
+        if p % prev_p:
+            pooled, prev_p = x, 1
+        pooled = ops.avgpool(pooled, p // prev_p)
+        prev_p = p
+        y = branches[j][1].fused(pooled, act=1, groups=groups)
+        outs[j] = ops.interpolate(y, size=x.shape[2:], mode='bilinear')
+    return ops.concat([x] + outs)
+
+
+class piramidNet2(nn.Module):
+    """models/dsnet_t2.py:1893-2083 (densenet backbone)."""
+
+    def __init__(self, pretrained=False, backbone='densenet'):
+        super().__init__()
+        if backbone != 'densenet':
+            raise NotImplementedError("only the densenet backbone (the shipped recipe) is on the native path")
+        self.backbone = backbone
+        self.resnet_features = densenet121(pretrained)
+        pv, cin = [128, 64, 32, 16, 8], [64, 128, 256]
+        for j in range(5):
+            setattr(self, 'branch0_%d' % j, _pool_branch(pv[j], cin[0]))
+        for j in range(4):
+            setattr(self, 'branch1_%d' % j, _pool_branch(pv[j + 1], cin[1]))
+        for j in range(3):
+            setattr(self, 'branch2_%d' % j, _pool_branch(pv[j + 2], cin[2]))
+
+    def forward(self, x, groups=1):
+        o = self.resnet_features(x, groups)
+        b0 = _pyramid([getattr(self, 'branch0_%d' % j) for j in range(5)], o[0], groups)
+        b1 = _pyramid([getattr(self, 'branch1_%d' % j) for j in range(4)], o[1], groups)
+        b2 = _pyramid([getattr(self, 'branch2_%d' % j) for j in range(3)], o[2], groups)
+        return o[0], o[1], o[2], o[3], o[4], b2, b1, b0
+
+
+def _c1x1(cin, cout):
+    return nn.Sequential(conv2dSame(cin, cout, 1, padding='same'), nn.ReLU(inplace=True))
+
+
+def _img_conv(cin):
+    return nn.Sequential(convbn(cin, 1, 5, 1, 'same', 2), nn.ReLU(inplace=True))
+
+
+class segNet(nn.Module):
+    """models/dsnet_t2.py:915-938."""
+
+    def __init__(self, in_channels, feature_channel, labels=8, pretrained=False, dropout=0):
+        super().__init__()
+        self.conv1d_1 = _c1x1(in_channels, 64)
+        self.Conv2DownUp1 = Conv2DownUp(64, 32, 3, dropout=dropout)
+        self.conv1d_2 = _c1x1(32 + feature_channel, 32)
+        self.Conv2DownUp2 = nn.Sequential(Conv2DownUp(32, 32, 3, lastLayer=False, dropout=dropout),
+                                          ConvTranspose2dSame(32, labels, 3, 1, padding='same', init_he=False))
+
+    def forward(self, x, input_a, input_b, xleft):
+        x = ops.interpolate(x, scale_factor=2, mode='nearest')
+        x = self.Conv2DownUp1(self.conv1d_1[0].run(x, act=1))
+        x1 = ops.interpolate(x, scale_factor=2, mode='nearest')
+        s = ops.interpolate(x, size=xleft.shape[2:], mode='nearest')
+        s = self.conv1d_2[0].run(ops.concat([s, xleft]), act=1)
+        s = self.Conv2DownUp2[1](self.Conv2DownUp2[0](s))
+        return x, x1, ops.interpolate(s, size=input_a.shape[2:], mode='nearest')
+
+
+class minidsnetExt(nn.Module):
+    """models/dsnet_t2.py:941-1299 — the network the shipped scripts train (`-net sdnet_mini_ext`), densenet backbone.
+    forward(left, right) -> (seg_branch, disp_out, seg_branch2, disp_out).  Both towers run as one batch of two
+    statistics groups (weights are shared; BatchNorm statistics stay per image side, as in the reference)."""
+
+    def __init__(self, CFG, labels=8, pretrained=False, patch_type='', include_edges=False, backbone='densenet'):
+        super().__init__()
+        if backbone != 'densenet' or CFG.multaskloss or CFG.hanet or include_edges:
+            raise NotImplementedError("native path: densenet backbone, no multitask loss / HANet / edge channel yet")
+        dropout = CFG.dropout
+        self.aspp_mod, self.use_att, self.convDeconvOut, self.abilation = CFG.aspp, CFG.use_att, CFG.convDeconvOut, CFG.abilation
+        self.patch_type, self.backbone = patch_type, backbone
+        feature_channel, inplane_seg2 = 1, 512
+        if self.aspp_mod == 1:
+            from .aspp import build_aspp
+            self.aspp, inplane_seg2 = build_aspp('densenet_a1', 32), 256
+        elif self.aspp_mod == 2:
+            from .aspp import build_aspp
+            self.aspp, inplane_seg2, feature_channel = build_aspp('densenet_a3', 32), 273, 64
+        self.resnet_features = piramidNet2(pretrained, backbone)
+        for j in range(4):
+            setattr(self, 'conv2d_ba%d' % j, _img_conv(3))
+        patch = (1, 17) if patch_type == '1dcorr' else (17, 17)
+        self.correlation_sampler = SpatialCorrelationSampler(1, patch, 1, 0, dilation_patch=1)
+        self.s2_corr_sampler = SpatialCorrelationSampler(1, patch, 1, 0, dilation_patch=1)
+        self.corrConv2d = _c1x1(patch[0] * patch[1], 128)
+        self.Conv2DownUp3 = Conv2DownUp(352 if 'no_dec1' in self.abilation else 32, 128, 3, dropout=dropout)
+        self.Conv2DownUp4 = Conv2DownUp(256, 64, 3, dropout=dropout)
+        self.segNet = segNet(2048, 1, labels, dropout=dropout)
+        self.conv1d_2 = _c1x1(65, 64)
+        self.Conv2DownUp5 = Conv2DownUp(64, 64, 5, lastLayer=False, dropout=dropout)
+        self.dispoutConv = ConvTranspose2dSame(64, 1, 5, padding='same', init_he=False)
+        self.conv1d_3 = _c1x1(96, 64)
+        self.conv1d_4 = _c1x1(inplane_seg2, 128)
+        self.Conv2DownUp6 = Conv2DownUp(128, 64, 3, dropout=dropout)
+        self.Conv2DownUp7 = Conv2DownUp(128, 64, 3, dropout=dropout)
+        self.Conv2DownUp8 = Conv2DownUp(32, 64, 3, dropout=dropout)
+        self.Conv2DownUp9 = Conv2DownUp(128, 64, 3, dropout=dropout)
+        self.conv1d_at_d = nn.Sequential(conv2dSame(64, 1, 1, padding='same'), nn.Sigmoid(), nn.Dropout(p=dropout))
+        self.conv1d_at_s = nn.Sequential(conv2dSame(64, 1, 1, padding='same'), nn.Sigmoid(), nn.Dropout(p=dropout))
+        c10 = 64 if 'no_dec3' in self.abilation else (128 if self.use_att else 192)
+        self.Conv2DownUp10 = Conv2DownUp(c10, 64, 3, dropout=dropout)
+        self.conv1d_5 = _c1x1(64 + feature_channel, 32)
+        if self.convDeconvOut:
+            self.Conv2DownUp11 = nn.Sequential(Conv2DownUp(32, 32, 3, lastLayer=False))
+            self.convOutput2 = conv2dSame(32, labels, 3, 1, padding='same')
+            if self.convDeconvOut == 2:
+                self.convOutput = ConvTranspose2dSame(32, labels, 3, 1, padding='same', init_he=False)
+        else:
+            self.Conv2DownUp11 = nn.Sequential(Conv2DownUp(32, 32, 3, lastLayer=False, dropout=dropout),
+                                               ConvTranspose2dSame(32, labels, 3, 1, padding='same', init_he=False))
+
+    def forward(self, input_a, input_b, pos=None, disp_gt=None, seg_gt=None):
+        _no_dropout(self.conv1d_at_d[2].p, self.training)
+        B = input_a.shape[0]
+        both = torch.cat([input_a, input_b], 0)
+        t = self.resnet_features(both, groups=2)          # taps of both towers, batch = [left | right]
+        a = [u[:B] for u in t]
+        b = [u[B:] for u in t]
+        xl3 = self.conv2d_ba3[0].fused(input_a, act=1)    # computed (and unused) exactly as in the reference
+        xl2 = self.conv2d_ba1[0].fused(input_a, act=1)
+        xl1 = self.conv2d_ba2[0].fused(input_a, act=1)
+        xl0 = self.conv2d_ba0[0].fused(input_a, act=1)
+        del xl3
+        x, x1, seg1 = self.segNet(ops.concat([a[4], b[4]]), input_a, input_b, xl0)
+
+        y = self.correlation_sampler(a[5], b[5])
+        if self.patch_type == '1dcorr':
+            y = torch.squeeze(y, 1)
+            y = self.corrConv2d[0].run(y, act=1)
+        else:
+            n, ph, pw, h, w = y.shape
+            y = y.reshape(n, ph * pw, h, w)
+            # the reference divides the 2-D correlation by C (models/dsnet_t2.py:1193); fold it into the 1x1 conv input
+            y = self.corrConv2d[0].run(ops.affine_act(y, _const(1.0 / a[5].size(1), ph * pw, y.device), None), act=1)
+        y1 = self.Conv2DownUp3(a[5] if 'no_dec1' in self.abilation else x1)
+        y1 = ops.interpolate(y1, size=y.shape[2:], mode='bilinear')
+        y = self.Conv2DownUp4(ops.concat([y1, y]))
+        y2 = ops.interpolate(y, scale_factor=8)
+        xl2 = ops.interpolate(xl2, size=y2.shape[2:], mode='bilinear')
+        d = self.Conv2DownUp5(self.conv1d_2[0].run(ops.concat([y2, xl2]), act=1))
+        disp = ops.interpolate(self.dispoutConv(d), size=input_a.shape[2:], mode='bilinear')
+
+        if self.aspp_mod == 1:
+            s2 = self.aspp(a[1])
+        elif self.aspp_mod == 2:
+            s2b = self.aspp(t[3], groups=2)
+            s21, s22 = s2b[:B], s2b[B:]
+            s2 = ops.concat([torch.squeeze(self.s2_corr_sampler(s21, s22), 1), s21])
+        else:
+            s2 = ops.concat([a[6], b[6]])
+        s2 = self.Conv2DownUp6(self.conv1d_4[0].run(s2, act=1))
+        y3 = ops.interpolate(y, size=s2.shape[2:])
+        if 'no_dec3' not in self.abilation:
+            x3 = ops.interpolate(self.Conv2DownUp8(x1), size=s2.shape[2:])
+            if self.use_att:
+                s2_d = self.Conv2DownUp7(ops.concat([s2, y3]))
+                at_d = self.conv1d_at_d[0].run(s2_d, act=2)
+                s2_s = self.Conv2DownUp9(ops.concat([s2, x3]))
+                at_s = self.conv1d_at_s[0].run(s2_s, act=2)
+                s2 = ops.concat([ops.mul_bcast(s2_d, at_s), ops.mul_bcast(s2_s, at_d)])
+            else:
+                s2 = ops.concat([s2, x3, y3])
+        s2 = self.Conv2DownUp10(s2)
+        if self.aspp_mod == 2:
+            s2 = ops.concat([ops.interpolate(s2, size=a[0].shape[2:]), a[0]])
+            seg2 = self.conv1d_5[0].run(s2, act=1)
+            seg2 = self.Conv2DownUp11[1](self.Conv2DownUp11[0](seg2))
+            seg2 = ops.interpolate(seg2, size=input_a.shape[2:], mode='nearest')
+        else:
+            s2 = ops.concat([ops.interpolate(s2, size=xl1.shape[2:]), xl1])
+            seg2 = self.conv1d_5[0].run(s2, act=1)
+            seg2 = self.Conv2DownUp11[0](seg2)
+            if self.convDeconvOut:
+                s = self.convOutput2(seg2)
+                seg2 = ops.affine_act(self.convOutput(seg2), None, None, s) if self.convDeconvOut == 2 else s
+            else:
+                seg2 = self.Conv2DownUp11[1](seg2)
+        return seg1, disp, seg2, disp
+
+
+def _const(v, n, device):
+    return torch.full((1, n), v, dtype=torch.float32, device=device)

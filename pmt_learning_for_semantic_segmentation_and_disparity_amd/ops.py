@@ -136,7 +136,7 @@ class ConvSpec:
 def _conv_launch(x, ldx, wp, y, ldy, bias, in_scale, in_shift, stats, B, H, W, Cin, Ho, Wo, Cout,
                  kh, kw, stride, dil, pad_t, pad_l, in_relu, groups, act, accumulate):
     call("sdhip_conv2d_fwd", ptr(x), ptr(wp), ptr(y), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(stats),
-         B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, stride, dil, pad_t, pad_l,
+         stats.stride(1) if stats is not None else 0, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, stride, dil, pad_t, pad_l,
          int(in_relu), groups, act, int(accumulate), dtype_code(x), stream_ptr())
 
 
@@ -173,13 +173,13 @@ class _ConvFn(torch.autograd.Function):
         g, ldg = nhwc_view(gy)
         if gstats is not None:      # gradient through the batch statistics of the BatchNorm that follows
             g2 = empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
-            call("sdhip_stats_fix", ptr(g), ldg, ptr(ysaved), Cout, ptr(g2), Cout, ptr(gstats.contiguous()),
+            call("sdhip_stats_fix", ptr(g), ldg, ptr(ysaved), Cout, ptr(g2), Cout, ptr(gstats), gstats.stride(1),
                  npix_o, Cout, groups, dt, stream_ptr())
             g, ldg = g2, Cout
         if act:                     # activation fused in the epilogue: derivative from the stored output
             g2 = empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
             call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(ysaved), Cout, ptr(g2), Cout, None, None, None, None,
-                 npix_o, Cout, 1, 1 if act == 1 else 4, dt, stream_ptr())
+                 npix_o, Cout, 1, 1 if act == 1 else 4, 0, dt, stream_ptr())
             g, ldg = g2, Cout
         gx = gscale = gshift = gw = gb = None
         T = spec.kh * spec.kw
@@ -197,7 +197,7 @@ class _ConvFn(torch.autograd.Function):
                 gscale = torch.empty_like(in_scale)
                 gshift = torch.empty_like(in_shift)
                 call("sdhip_affine_act_bwd", ptr(gpost), Cin, ptr(xv), ldx, ptr(gx), Cin, ptr(in_scale), ptr(in_shift),
-                     ptr(gscale), ptr(gshift), B * H * W, Cin, groups, 1 if ctx.in_relu else 0, dt, stream_ptr())
+                     ptr(gscale), ptr(gshift), B * H * W, Cin, groups, 1 if ctx.in_relu else 0, 0, dt, stream_ptr())
             else:
                 gx = gpost
         elif in_scale is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
@@ -269,7 +269,7 @@ class _BNFinalizeFn(torch.autograd.Function):
         shift = torch.empty((groups, C), dtype=torch.float32, device=dev)
         mean = torch.empty((groups, C), dtype=torch.float32, device=dev)
         invstd = torch.empty((groups, C), dtype=torch.float32, device=dev)
-        call("sdhip_bn_finalize", ptr(stats), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+        call("sdhip_bn_finalize", ptr(stats), stats.stride(1) if stats is not None else 0, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
              ptr(scale), ptr(shift), ptr(mean), ptr(invstd), C, groups, float(count), float(eps),
              float(momentum), stream_ptr())
         ctx.save_for_backward(gamma, mean, invstd)
@@ -285,7 +285,7 @@ class _BNFinalizeFn(torch.autograd.Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         dstats = torch.empty((groups, 2, C), dtype=torch.float64, device=dev) if train else None
         call("sdhip_bn_finalize_bwd", ptr(gscale.contiguous()), ptr(gshift.contiguous()), ptr(gamma), ptr(mean), ptr(invstd),
-             ptr(dgamma), ptr(dbeta), ptr(dstats), C, groups, count, int(train), stream_ptr())
+             ptr(dgamma), ptr(dbeta), ptr(dstats), C, 0, C, groups, count, int(train), stream_ptr())
         return dstats, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -329,7 +329,7 @@ class _AffineActFn(torch.autograd.Function):
         gscale = torch.empty_like(scale) if need else None
         gshift = torch.empty_like(shift) if need else None
         call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(xv), ldx, ptr(gx), C, ptr(scale), ptr(shift), ptr(gscale), ptr(gshift),
-             B * H * W, C, groups, act, dtype_code(xv), stream_ptr())
+             B * H * W, C, groups, act, 0, dtype_code(xv), stream_ptr())
         return gx, gscale, gshift, (gy if has_res else None), None, None
 
 
@@ -349,7 +349,7 @@ class _ChannelStatsFn(torch.autograd.Function):
         B, C, H, W = x.shape
         xv, ldx = nhwc_view(x)
         stats = torch.empty((groups, 2, C), dtype=torch.float64, device=x.device)
-        call("sdhip_channel_stats", ptr(xv), ldx, ptr(stats), B * H * W, C, groups, 1, dtype_code(x), stream_ptr())
+        call("sdhip_channel_stats", ptr(xv), ldx, ptr(stats), C, B * H * W, C, groups, 1, dtype_code(x), stream_ptr())
         ctx.save_for_backward(xv)
         ctx.cfg = (ldx, groups)
         return stats
@@ -361,6 +361,174 @@ class _ChannelStatsFn(torch.autograd.Function):
         B, C, H, W = xv.shape
         zero = torch.zeros((B, H, W, C), dtype=xv.dtype, device=xv.device).permute(0, 3, 1, 2)
         gx = empty_nhwc(B, C, H, W, xv.dtype, xv.device)
-        call("sdhip_stats_fix", ptr(zero), C, ptr(xv), ldx, ptr(gx), C, ptr(gstats.contiguous()), B * H * W, C, groups,
+        call("sdhip_stats_fix", ptr(zero), C, ptr(xv), ldx, ptr(gx), C, ptr(gstats), gstats.stride(1), B * H * W, C, groups,
              dtype_code(xv), stream_ptr())
         return gx, None
+
+
+# ============================================================================ pooling / resize / concat / broadcast product
+class _MaxPool3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        B, C, H, W = x.shape
+        xv, ldx = nhwc_view(x)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = empty_nhwc(B, C, Ho, Wo, x.dtype, x.device)
+        idx = torch.empty((B * Ho * Wo, C), dtype=torch.uint8, device=x.device)
+        call("sdhip_maxpool3s2_fwd", ptr(xv), ldx, ptr(y), C, ptr(idx), B, H, W, C, dtype_code(x), stream_ptr())
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        g, ldg = nhwc_view(gy)
+        gx = empty_nhwc(B, C, H, W, gy.dtype, gy.device)
+        call("sdhip_maxpool3s2_bwd", ptr(g), ldg, ptr(idx), ptr(gx), C, B, H, W, C, dtype_code(gy), stream_ptr())
+        return gx
+
+
+def maxpool3s2(x):
+    return _MaxPool3s2Fn.apply(x)
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        _require_gpu(x)
+        B, C, H, W = x.shape
+        xv, ldx = nhwc_view(x)
+        y = empty_nhwc(B, C, H // k, W // k, x.dtype, x.device)
+        call("sdhip_avgpool_fwd", ptr(xv), ldx, ptr(y), C, B, H, W, C, k, dtype_code(x), stream_ptr())
+        ctx.cfg = (B, C, H, W, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, H, W, k = ctx.cfg
+        g, ldg = nhwc_view(gy)
+        gx = empty_nhwc(B, C, H, W, gy.dtype, gy.device)
+        call("sdhip_avgpool_bwd", ptr(g), ldg, ptr(gx), C, B, H, W, C, k, dtype_code(gy), stream_ptr())
+        return gx, None
+
+
+def avgpool(x, k):
+    """k x k / stride k average pool.  Large windows are built as a chain of <= 8 x 8 pools (mean of equal-size
+    means), which keeps every launch wide; nn.AvgPool2d(128) of a 128x256 map would otherwise be 2 serial threads."""
+    while k > 8 and k % 2 == 0:
+        step = 8 if k % 8 == 0 else 2
+        x = _AvgPoolFn.apply(x, step)
+        k //= step
+    return _AvgPoolFn.apply(x, k) if k > 1 else x
+
+
+_MODES = {'nearest': 0, 'bilinear': 1, 'bilinear_ac': 2}
+
+
+class _ResizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, mode, scale_h, scale_w, out):
+        _require_gpu(x)
+        B, C, H, W = x.shape
+        xv, ldx = nhwc_view(x)
+        if out is None:
+            y, ldy = empty_nhwc(B, C, Ho, Wo, x.dtype, x.device), C
+        else:
+            y, ldy = out, out.stride(3)
+        call("sdhip_resize_fwd", ptr(xv), ldx, ptr(y), ldy, B, H, W, C, Ho, Wo, mode, scale_h, scale_w, dtype_code(x), stream_ptr())
+        ctx.cfg = (B, C, H, W, Ho, Wo, mode, scale_h, scale_w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, H, W, Ho, Wo, mode, scale_h, scale_w = ctx.cfg
+        g, ldg = nhwc_view(gy)
+        gx = empty_nhwc(B, C, H, W, gy.dtype, gy.device)
+        tmp = torch.empty(B * Ho * W * C, dtype=torch.float32, device=gy.device)
+        call("sdhip_resize_bwd", ptr(g), ldg, ptr(gx), C, ptr(tmp), B, H, W, C, Ho, Wo, mode, scale_h, scale_w,
+             dtype_code(gy), stream_ptr())
+        return gx, None, None, None, None, None, None
+
+
+def interpolate(x, size=None, scale_factor=None, mode='nearest', align_corners=None):
+    """F.interpolate for the modes on the hot path.  A same-size nearest / bilinear(align_corners=False) resize is the
+    identity (source index == destination index, lambda == 0) and is skipped."""
+    B, C, H, W = x.shape
+    if size is not None:
+        Ho, Wo = (size, size) if isinstance(size, int) else (int(size[0]), int(size[1]))
+        sh = sw = 0.0
+    else:
+        Ho, Wo = int(H * scale_factor), int(W * scale_factor)
+        sh = sw = 1.0 / float(scale_factor)   # ATen uses the user scale when recompute_scale_factor is unset
+    if mode == 'bilinear' and align_corners:
+        m = 2
+    elif mode in ('nearest', 'bilinear'):
+        m = _MODES[mode]
+    else:
+        raise _lib.SdhipError("interpolate mode %r is not on the hot path" % mode)
+    if (Ho, Wo) == (H, W) and m != 2:
+        return x
+    return _ResizeFn.apply(x, Ho, Wo, m, sh, sw, None)
+
+
+class _ConcatFn(torch.autograd.Function):
+    """torch.cat(dim=1) as copies into channel slices of one NHWC slab; the backward is free (views)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        _require_gpu(*xs)
+        B, _, H, W = xs[0].shape
+        Ct = sum(t.shape[1] for t in xs)
+        out = empty_nhwc(B, Ct, H, W, xs[0].dtype, xs[0].device)
+        off, offs = 0, []
+        for t in xs:
+            C = t.shape[1]
+            tv, ld = nhwc_view(t)
+            dst = out[:, off:off + C]
+            call("sdhip_affine_act", ptr(tv), ld, ptr(dst), Ct, None, 0, None, None, B * H * W, C, 1, 0, dtype_code(t), stream_ptr())
+            offs.append((off, C))
+            off += C
+        ctx.offs = offs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g[:, o:o + c] for o, c in ctx.offs)
+
+
+def concat(xs):
+    return _ConcatFn.apply(*xs)
+
+
+class _MulBcastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, m):
+        _require_gpu(a, m)
+        B, C, H, W = a.shape
+        av, lda = nhwc_view(a)
+        mv, ldm = nhwc_view(m)
+        y = empty_nhwc(B, C, H, W, a.dtype, a.device)
+        call("sdhip_mul_bcast_fwd", ptr(av), lda, ptr(mv), ldm, ptr(y), C, B * H * W, C, dtype_code(a), stream_ptr())
+        ctx.save_for_backward(av, mv)
+        ctx.cfg = (lda, ldm)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        av, mv = ctx.saved_tensors
+        lda, ldm = ctx.cfg
+        B, C, H, W = av.shape
+        gv, ldg = nhwc_view(g)
+        ga = empty_nhwc(B, C, H, W, av.dtype, av.device)
+        gm = empty_nhwc(B, 1, H, W, av.dtype, av.device)
+        call("sdhip_mul_bcast_bwd", ptr(gv), ldg, ptr(av), lda, ptr(mv), ldm, ptr(ga), C, ptr(gm), 1, B * H * W, C,
+             dtype_code(av), stream_ptr())
+        return ga, gm
+
+
+def mul_bcast(a, m):
+    """a (B,C,H,W) * m (B,1,H,W)."""
+    return _MulBcastFn.apply(a, m)

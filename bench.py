@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""Headline benchmark: stereo-pairs/s of one training step (forward + loss + backward + Adam) of the joint
+segmentation + disparity network on synthetic S-ROSeS-shaped 512x256 (WxH) batches.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL; per-GPU batch fixed => weak scaling)
+
+Prints ONE JSON line on rank 0 (contract in the round prompt) including
+  roofline     : the dominant kernel (5x5 64->64 conv of Conv2DownUp5) timed with HIP events on its own stream,
+                 algorithmic FLOPs / launch time vs the dense bf16 MFMA peak;
+  cpu_baseline : the CPU oracle (oracle/ref_models.py, "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="stereo pairs per GPU (shipped recipe: -b 8)")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def build_model(dtype):
+    from oracle.ref_models import CFG  # plain attribute bag (the argparse fields the model reads); no compute
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    torch.manual_seed(0)
+    m = N.minidsnetExt(CFG(dropout=0.0, aspp=0, use_att=1), labels=2, pretrained=False, patch_type='1dcorr', backbone='densenet')
+    return m.cuda().train()
+
+
+def kernel_roofline(dtype, B, H, W):
+    """Time the dominant kernel alone: conv2dSame 5x5 64->64 at full resolution (Conv2DownUp5.c1-c3, 63 % of the FLOPs)."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd._lib import call, ptr
+    C = 64
+    x = torch.randn(B, H, W, C, device="cuda").to(dtype).permute(0, 3, 1, 2)
+    w = torch.randn(C, C, 5, 5, device="cuda") * 0.03
+    wp = ops.packed_weight(w, 'conv', 'fwd', dtype)
+    y = ops.empty_nhwc(B, C, H, W, dtype, "cuda")
+    st = torch.zeros(1, 2, C, dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    n = 20
+    with torch.cuda.stream(s):
+        def launch():
+            ops._conv_launch(x, C, wp, y, C, None, None, None, st, B, H, W, C, H, W, C, 5, 5, 1, 1, 2, 2, False, 1, 0, False)
+        for _ in range(3):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(n):
+            launch()
+        e1.record(s)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 2.0 * B * H * W * C * C * 25
+    peak = 2500.0 if dtype == torch.bfloat16 else 157.3
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_fwd_kernel<8x32 tile> 5x5 64->64 @%dx%dx%d" % (B, H, W), "achieved": round(ach, 2),
+            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "ms_per_launch": round(ms, 4)}
+
+
+def cpu_baseline(B, H, W, steps):
+    """The CPU oracle (a port of the reference graph to plain torch.nn) on the host cores: fwd + loss + bwd."""
+    import torch.nn.functional as F
+    from oracle import ref_models as R
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.ops import _lovasz_softmax_torch
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import synthetic_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = R.minidsnetExt(R.CFG(), labels=2, patch_type='1dcorr').train()
+    left, right, seg, disp = synthetic_batch(B, H, W, device="cpu")
+    ts = []
+    for i in range(steps + 1):
+        t0 = time.time()
+        o = m(left, right)
+        ce = lambda y: torch.mean(torch.sum(-seg * F.log_softmax(y, 1), 1))
+        loss = ce(o[0]) + ce(o[2]) + _lovasz_softmax_torch(o[2], seg) + F.l1_loss(o[1], disp)
+        m.zero_grad(set_to_none=True)
+        loss.backward()
+        ts.append(time.time() - t0)
+    t = sum(ts[1:]) / max(1, len(ts) - 1)   # first step is warm-up
+    return {"value": round(B / t, 4), "unit": "stereo-pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of B=%d %dx%d fp32 fwd+loss+bwd after 1 warm-up (oracle/ref_models.py)" % (steps, B, W, H)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")   # RCCL on ROCm; MASTER_ADDR/PORT from the launcher env
+        pg = dist.group.WORLD
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    model = build_model(dtype)
+    step = TrainStep(model, dtype=dtype, use_graph=not a.no_graph, world_size=world, process_group=pg)
+    batch = synthetic_batch(a.batch, a.height, a.width, seed=1234 + rank)
+    for _ in range(a.warmup):
+        loss = step(*batch)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step(*batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    lossv = float(loss.item())
+    if rank == 0:
+        out = {"metric": "stereo-pairs/sec (train fwd+bwd) 512x256", "value": round(a.batch * world * a.steps / dt, 3),
+               "unit": "stereo-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": "minidsnetExt (densenet121, 1dcorr, aspp 0; the live PyTorch form of baseline_SDnet*) "
+                                      "train step fwd+loss(CE+CE+Lovasz+L1)+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s"
+                                      % (a.width, a.height, a.batch, "hipGraph" if not a.no_graph else "eager"),
+                          "global_batch": a.batch * world, "parallelism": "dp%d" % world},
+               "loss": round(lossv, 5)}
+        if not a.no_roofline:
+            out["roofline"] = kernel_roofline(dtype, a.batch, a.height, a.width)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(2, a.height, a.width, a.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

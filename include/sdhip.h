@@ -186,6 +186,23 @@ int sdhip_mul_bcast_fwd(const void* a, int lda, const void* m, int ldm, void* y,
 int sdhip_mul_bcast_bwd(const void* g, int ldg, const void* a, int lda, const void* m, int ldm,
                         void* ga, int ldga, void* gm, int ldgm, long npix, int C, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Tail of the training step.
+ * ------------------------------------------------------------------------- */
+/* Adam over ONE flat f32 buffer (torch.optim.Adam semantics, torch_implementation.py:718-724: lr 0.0015,
+ * eps 1e-7).  beta_pow = {beta1^t, beta2^t} lives on the device and is advanced by the call, so the step can
+ * be replayed from a hipGraph.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+int sdhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* beta_pow,
+                    long n, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                    void* stream);
+/* loss += weight * mean_p sum_c -target[p,c]*log_softmax(logits[p,:])_c  and (optionally) its gradient w.r.t. the
+ * logits: categoricalCrossEntropy(F.log_softmax(y,1), gt) of util/utilTorchLoss.py:373-378.  target is f32. */
+int sdhip_ce_loss(const void* logits, int ldy, const float* target, int ldt, void* grad, int ldg, double* loss,
+                  long npix, int C, float weight, int dtype, void* stream);
+/* loss += weight * mean |pred - target| (nn.L1Loss, losses/multiLosses.py:141) and its gradient. */
+int sdhip_l1_loss(const void* pred, const float* target, void* grad, double* loss, long n, float weight,
+                  int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

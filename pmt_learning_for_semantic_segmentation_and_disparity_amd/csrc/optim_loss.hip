@@ -1,0 +1,143 @@
+// Training-step tail for gfx950: fused Adam over one flat parameter buffer, and the per-pixel
+// losses of the timed step (categorical cross-entropy on log-softmax, L1), forward + gradient in one pass.
+//
+// Replaces torch.optim.Adam(lr=0.0015, eps=1e-7) (torch_implementation.py:718-724),
+// categoricalCrossEntropy (util/utilTorchLoss.py:373-378, fed by F.log_softmax at
+// losses/multiLosses.py:42) and nn.L1Loss (losses/multiLosses.py:141).
+#include "sdhip_common.h"
+
+namespace {
+
+// state[0] = beta1^t, state[1] = beta2^t (device resident so the step is graph-replayable)
+__global__ void adam_tick_kernel(float* state, float b1, float b2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { state[0] *= b1; state[1] *= b2; }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float wd, float gscale, const float* __restrict__ state) {
+  const float bc1 = 1.f - state[0], bc2 = 1.f - state[1];
+  const float step = lr / bc1, ibc2 = 1.f / sqrtf(bc2);
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      f32x4 pv = *reinterpret_cast<f32x4*>(p + i), gv = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mv = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gr = gv[e] * gscale + wd * pv[e];
+        mv[e] = b1 * mv[e] + (1.f - b1) * gr;
+        vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+        pv[e] -= step * mv[e] / (sqrtf(vv[e]) * ibc2 + eps);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pv; *reinterpret_cast<f32x4*>(m + i) = mv; *reinterpret_cast<f32x4*>(v + i) = vv;
+    } else {
+      for (long j = i; j < n; ++j) {
+        const float gr = g[j] * gscale + wd * p[j];
+        m[j] = b1 * m[j] + (1.f - b1) * gr;
+        v[j] = b2 * v[j] + (1.f - b2) * gr * gr;
+        p[j] -= step * m[j] / (sqrtf(v[j]) * ibc2 + eps);
+      }
+    }
+  }
+}
+
+// block reduce of one float, result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+  return r;
+}
+
+// loss += weight/npix * sum_p sum_c -t[p,c] * log_softmax(y[p,:])_c ;  gy[p,c] = weight/npix * (softmax_c * sum_c t - t_c)
+template <typename T>
+__global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ t, int ldt,
+                                                 T* __restrict__ gy, int ldg, double* __restrict__ loss, long npix, int C, float wnorm) {
+  __shared__ float sh[4];
+  float part = 0.f;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+    const T* yp = y + p * ldy;
+    const float* tp = t + p * ldt;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, Elem<T>::ld(yp + c));
+    float se = 0.f, ts = 0.f, dot = 0.f;
+    for (int c = 0; c < C; ++c) { const float z = Elem<T>::ld(yp + c) - mx; se += __expf(z); ts += tp[c]; dot += tp[c] * z; }
+    const float lse = __logf(se);
+    part += ts * lse - dot;  // sum_c -t_c (z_c - lse)
+    if (gy) {
+      const float inv = 1.f / se;
+      for (int c = 0; c < C; ++c) {
+        const float sm = __expf(Elem<T>::ld(yp + c) - mx) * inv;
+        Elem<T>::st(gy + p * ldg + c, wnorm * (sm * ts - tp[c]));
+      }
+    }
+  }
+  const float tot = block_sum(part, sh);
+  if (threadIdx.x == 0) atomicAdd(loss, (double)tot * (double)wnorm);
+}
+
+// loss += weight/n * sum |a - b| ; ga = weight/n * sign(a - b)
+template <typename T>
+__global__ __launch_bounds__(256) void l1_kernel(const T* __restrict__ a, const float* __restrict__ b, T* __restrict__ ga,
+                                                 double* __restrict__ loss, long n, float wnorm) {
+  __shared__ float sh[4];
+  float part = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = Elem<T>::ld(a + i) - b[i];
+    part += fabsf(d);
+    if (ga) Elem<T>::st(ga + i, d > 0.f ? wnorm : (d < 0.f ? -wnorm : 0.f));
+  }
+  const float tot = block_sum(part, sh);
+  if (threadIdx.x == 0) atomicAdd(loss, (double)tot * (double)wnorm);
+}
+
+inline dim3 grid_for(long items) {
+  long b = (items + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+}  // namespace
+
+extern "C" int sdhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* beta_pow,
+                               long n, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                               void* stream) {
+  SDHIP_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && beta_pow && n > 0, "adam_step: bad arguments");
+  SDHIP_CHECK_ARG((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                  "adam_step: buffers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, beta_pow, beta1, beta2);
+  hipLaunchKernelGGL(adam_kernel, grid_for((n + 3) / 4), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n, lr, beta1,
+                     beta2, eps, weight_decay, grad_scale, beta_pow);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_ce_loss(const void* logits, int ldy, const float* target, int ldt, void* grad, int ldg, double* loss,
+                             long npix, int C, float weight, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(logits && target && loss && npix > 0 && C > 0 && ldy >= C && ldt >= C && (!grad || ldg >= C), "ce_loss: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "ce_loss: unknown dtype %d", dtype);
+  const float wn = weight / (float)npix;
+  if (dtype == SDHIP_F32)
+    hipLaunchKernelGGL(ce_kernel<float>, grid_for(npix), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ldy, target, ldt, (float*)grad, ldg, loss, npix, C, wn);
+  else
+    hipLaunchKernelGGL(ce_kernel<bf16_t>, grid_for(npix), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ldy, target, ldt, (bf16_t*)grad, ldg, loss, npix, C, wn);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_l1_loss(const void* pred, const float* target, void* grad, double* loss, long n, float weight,
+                             int dtype, void* stream) {
+  SDHIP_CHECK_ARG(pred && target && loss && n > 0, "l1_loss: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "l1_loss: unknown dtype %d", dtype);
+  const float wn = weight / (float)n;
+  if (dtype == SDHIP_F32)
+    hipLaunchKernelGGL(l1_kernel<float>, grid_for(n), dim3(256), 0, (hipStream_t)stream, (const float*)pred, target, (float*)grad, loss, n, wn);
+  else
+    hipLaunchKernelGGL(l1_kernel<bf16_t>, grid_for(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, target, (bf16_t*)grad, loss, n, wn);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}

@@ -84,6 +84,12 @@ def correlation(in1, in2, patch_h, patch_w, dilation_patch=1):
 import weakref
 
 _pack_cache = {}   # id(weight parameter) -> (weakref, {(mode, dtype): (version, packed)})
+_pack_generation = [0]
+
+
+def invalidate_packed_weights():
+    """Call after parameters were changed outside autograd's version tracking (the fused Adam kernel)."""
+    _pack_generation[0] += 1
 
 
 def _cache_entry(weight):
@@ -111,7 +117,8 @@ def packed_weight(weight, kind, mode, dtype):
     ent = _cache_entry(weight)
     key = (mode, dtype)
     hit = ent.get(key)
-    if hit is not None and hit[0] == weight._version and not torch.cuda.is_current_stream_capturing():
+    ver = (weight._version, _pack_generation[0])
+    if hit is not None and hit[0] == ver and not torch.cuda.is_current_stream_capturing():
         return hit[1]
     M, K, sm, sk, flip = _pack_params(kind, mode, Cout, Cin, T)
     dt = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
@@ -120,7 +127,7 @@ def packed_weight(weight, kind, mode, dtype):
     if not w.is_contiguous():
         w = w.contiguous()
     call("sdhip_conv_pack_weights", ptr(w), ptr(buf), M, K, T, sm, sk, flip, dt, stream_ptr())
-    ent[key] = (weight._version, buf)
+    ent[key] = (ver, buf)
     return buf
 
 
@@ -532,3 +539,74 @@ class _MulBcastFn(torch.autograd.Function):
 def mul_bcast(a, m):
     """a (B,C,H,W) * m (B,1,H,W)."""
     return _MulBcastFn.apply(a, m)
+
+
+# ============================================================================ losses of the timed step
+def _lovasz_softmax_torch(logits, labels_onehot):
+    """Lovasz-softmax (util/lovasz_losses.py:153-199, classes='present') on the GPU with ATen sort/cumsum.
+    TRANSITIONAL: the only piece of the step that is not a hand-written kernel yet."""
+    B, C, H, W = logits.shape
+    p = torch.softmax(logits.float(), 1).permute(0, 2, 3, 1).reshape(-1, C)
+    fg_all = labels_onehot.permute(0, 2, 3, 1).reshape(-1, C)
+    total = p.new_zeros(())
+    present = p.new_zeros(())
+    for c in range(C):
+        fg = fg_all[:, c]
+        err = (fg - p[:, c]).abs()
+        err_s, perm = torch.sort(err, 0, descending=True)
+        fg_s = fg[perm]
+        gts = fg_s.sum()
+        inter = gts - fg_s.cumsum(0)
+        union = gts + (1.0 - fg_s).cumsum(0)
+        jac = 1.0 - inter / union
+        jac = torch.cat([jac[:1], jac[1:] - jac[:-1]])
+        has = (gts > 0).to(p.dtype)
+        total = total + has * torch.dot(err_s, jac.detach())
+        present = present + has
+    return total / present.clamp_min(1.0)
+
+
+class _TrainLossFn(torch.autograd.Function):
+    """total = CE(seg1) + CE(seg2) [+ Lovasz(seg2)] + L1(disp)  — the loss of the reference's training step
+    (torch_implementation.py:279,293,304,325 with `-loss cross_entropy lovasz_loss`).  The gradients w.r.t. the
+    three network outputs are produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, seg1, disp, seg2, seg_t, disp_t, use_lovasz):
+        _require_gpu(seg1, disp, seg2, seg_t, disp_t)
+        B, C, H, W = seg1.shape
+        npix = B * H * W
+        dt = dtype_code(seg1)
+        loss = torch.zeros(1, dtype=torch.float64, device=seg1.device)
+        tv, ldt = nhwc_view(seg_t)
+        grads = []
+        for s in (seg1, seg2):
+            sv, ld = nhwc_view(s)
+            g = empty_nhwc(B, C, H, W, s.dtype, s.device)
+            call("sdhip_ce_loss", ptr(sv), ld, ptr(tv), ldt, ptr(g), C, ptr(loss), npix, C, 1.0, dt, stream_ptr())
+            grads.append(g)
+        dv, ldd = nhwc_view(disp)
+        if ldd != 1 or not disp_t.is_contiguous():
+            raise _lib.SdhipError("disparity tensors must be dense (B,1,H,W)")
+        gd = torch.empty_like(dv)
+        call("sdhip_l1_loss", ptr(dv), ptr(disp_t), ptr(gd), ptr(loss), npix, 1.0, dt, stream_ptr())
+        total = loss
+        if use_lovasz:
+            with torch.enable_grad():
+                s2 = seg2.detach().requires_grad_(True)
+                lov = _lovasz_softmax_torch(s2, seg_t)
+                (g2,) = torch.autograd.grad(lov, s2)
+            grads[1] = grads[1] + g2.to(grads[1].dtype)
+            total = loss + lov.detach().double()
+        ctx.save_for_backward(grads[0], gd, grads[1])
+        return total.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        g1, gd, g2 = ctx.saved_tensors
+        return g1, gd, g2, None, None, None   # d(total)/d(total) is 1 in the training step
+
+
+def train_loss(seg1, disp, seg2, seg_target, disp_target, use_lovasz=True):
+    """seg_target: one-hot f32 (B,C,H,W); disp_target: f32 (B,1,H,W)."""
+    return _TrainLossFn.apply(seg1, disp, seg2, seg_target, disp_target, use_lovasz)

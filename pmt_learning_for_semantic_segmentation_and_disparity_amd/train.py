@@ -1,0 +1,106 @@
+"""Training step of the hot path: forward + loss + backward + Adam, optionally captured as ONE hipGraph.
+
+Counterpart of train_model's inner loop (torch_implementation.py:350-397) without its host-side metric /
+JPEG work: model(left, right) -> CE(seg1) + CE(seg2) + Lovasz(seg2) + L1(disp) -> backward -> Adam.
+Parameters live in one flat f32 buffer (one fused Adam launch, one gradient all-reduce over RCCL when
+data-parallel); activations run in `dtype` (bf16 MFMA path or exact f32 path).
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import call, ptr, stream_ptr
+
+
+def flatten_parameters(model):
+    """Re-home every parameter into one contiguous f32 buffer (and its .grad into a second one)."""
+    params = [p for p in model.parameters()]
+    n = sum(((p.numel() + 3) // 4) * 4 for p in params)     # 16-byte aligned slices
+    dev = params[0].device
+    flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+    flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            k = p.numel()
+            flat_p[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = flat_p[off:off + k].view(p.shape)
+            p.grad = flat_g[off:off + k].view(p.shape)
+            off += ((k + 3) // 4) * 4
+    return flat_p, flat_g
+
+
+class TrainStep:
+    def __init__(self, model, dtype=torch.bfloat16, lr=0.0015, betas=(0.9, 0.999), eps=1e-7, use_lovasz=True,
+                 use_graph=True, world_size=1, process_group=None):
+        self.model, self.dtype, self.use_lovasz = model, dtype, use_lovasz
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.world_size, self.pg = world_size, process_group
+        self.flat_p, self.flat_g = flatten_parameters(model)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.beta_pow = torch.ones(2, dtype=torch.float32, device=self.flat_p.device)
+        self.use_graph = use_graph
+        self.graph = None
+        self.static = None
+        self.loss = None
+
+    # -- pieces ---------------------------------------------------------------------------------
+    def forward_backward(self, left, right, seg, disp):
+        self.flat_g.zero_()
+        outs = self.model(left.to(self.dtype), right.to(self.dtype))
+        loss = ops.train_loss(outs[0], outs[1], outs[2], seg, disp, self.use_lovasz)
+        loss.backward()
+        return loss.detach()
+
+    def all_reduce(self):
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.flat_g, group=self.pg)   # RCCL sum over xGMI; Adam divides by world_size
+
+    def optimizer_step(self):
+        call("sdhip_adam_step", ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.beta_pow),
+             self.flat_p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, 0.0, 1.0 / self.world_size, stream_ptr())
+        ops.invalidate_packed_weights()
+
+    def _eager(self, left, right, seg, disp):
+        loss = self.forward_backward(left, right, seg, disp)
+        self.all_reduce()
+        self.optimizer_step()
+        return loss
+
+    # -- public ---------------------------------------------------------------------------------
+    def capture(self, left, right, seg, disp, warmup=2):
+        """Warm up eagerly on a side stream, then record forward+backward(+all-reduce)+Adam as one hipGraph."""
+        self.static = [t.clone() for t in (left, right, seg, disp)]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._eager(*self.static)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._eager(*self.static)
+        return self
+
+    def __call__(self, left, right, seg, disp):
+        if not self.use_graph:
+            return self._eager(left, right, seg, disp)
+        if self.graph is None:
+            self.capture(left, right, seg, disp)
+        for dst, src in zip(self.static, (left, right, seg, disp)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.loss
+
+
+def synthetic_batch(B, H, W, labels=2, device="cuda", seed=1234):
+    """S-ROSeS-shaped synthetic batch (tensor contract of util/utilTorchDataLoader.py:176-258,608-630)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    left = torch.rand((B, 3, H, W), generator=g)
+    right = torch.rand((B, 3, H, W), generator=g)
+    lab = torch.randint(0, labels, (B, H, W), generator=g)
+    seg = torch.nn.functional.one_hot(lab, labels).permute(0, 3, 1, 2).float().contiguous()
+    disp = (torch.rand((B, 1, H, W), generator=g) * 8.0 * seg[:, 1:2] + 0.1).contiguous()
+    return [t.to(device) for t in (left, right, seg, disp)]

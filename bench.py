@@ -55,12 +55,12 @@ def kernel_roofline(dtype, B, H, W):
     w = torch.randn(C, C, 5, 5, device="cuda") * 0.03
     wp = ops.packed_weight(w, 'conv', 'fwd', dtype)
     y = ops.empty_nhwc(B, C, H, W, dtype, "cuda")
-    st = torch.zeros(1, 2, C, dtype=torch.float64, device="cuda")
+    st = torch.zeros(ops.NREP, 1, 2, C, dtype=torch.float64, device="cuda")
     s = torch.cuda.Stream()
     n = 20
     with torch.cuda.stream(s):
         def launch():
-            ops._conv_launch(x, C, wp, y, C, None, None, None, st, B, H, W, C, H, W, C, 5, 5, 1, 1, 2, 2, False, 1, 0, False)
+            ops._conv_launch(x, C, wp, y, C, None, None, None, st, B, H, W, C, H, W, C, 5, 5, 1, 1, 2, 2, False, 1, 0, False, ops.NREP)
         for _ in range(3):
             launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -98,14 +98,16 @@ int sdhip_conv_unpack_wgrad(const float* acc, float* grad, int M, int K, int T,
  *            that precedes the conv, models/densenet.py:41-45,75-93); zero padding is applied AFTER pro;
  *   g      = b / (B/groups): statistics group of image b (left/right tower passes share a launch);
  *   stats  : if non-NULL, f64 [groups][2][stats_ld >= Cout] (stats_ld <= 0 means Cout; a slice of a wider
- *            statistics slab is addressed by offsetting the pointer); the kernel ADDS sum(y) and sum(y^2) over pixels
+ *            statistics slab is addressed by offsetting the pointer), replicated stats_nrep times
+ *            ([nrep][groups][2][stats_ld]; workgroups spread their atomics over the replicas because thousands
+ *            of adds into one 256-byte line serialise; consumers sum the replicas); the kernel ADDS sum(y) and sum(y^2) over pixels
  *            (of the stored, rounded values) — the batch statistics of the BatchNorm that follows;
  *   act    : 0 none, 1 ReLU, 2 sigmoid;  accumulate != 0: y += result.
  * (pad_t, pad_l) is the top/left padding; bottom/right padding is implied by (Ho, Wo)
  * (TF-"same" padding of models/torch_model.py:276-281 is asymmetric for stride 2). */
 int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                      const float* bias, const float* in_scale, const float* in_shift,
-                     double* stats, int stats_ld,
+                     double* stats, int stats_ld, int stats_nrep,
                      int B, int H, int W, int Cin, int ldx,
                      int Ho, int Wo, int Cout, int ldy,
                      int kh, int kw, int stride, int dil, int pad_t, int pad_l,
@@ -129,17 +131,17 @@ int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* d
  * f64 [groups][2][stats_ld] (stats_ld <= 0: = C), so a channel slice of a wider slab can be addressed.
  * ------------------------------------------------------------------------- */
 /* stats[g][0][c] += sum x, stats[g][1][c] += sum x^2 (f64). */
-int sdhip_channel_stats(const void* x, int ldx, double* stats, int stats_ld, long npix, int C, int groups,
+int sdhip_channel_stats(const void* x, int ldx, double* stats, int stats_ld, int stats_nrep, long npix, int C, int groups,
                         int zero_first, int dtype, void* stream);
 /* Train (stats != NULL): mean = S1/count, var = S2/count - mean^2 (biased), scale = gamma*invstd,
  * shift = beta - mean*scale; running_mean/var updated in place group by group with `momentum`
  * (running_var unbiased).  Eval (stats == NULL): scale/shift from the running statistics. */
-int sdhip_bn_finalize(const double* stats, int stats_ld, const float* gamma, const float* beta,
+int sdhip_bn_finalize(const double* stats, int stats_ld, int stats_nrep, const float* gamma, const float* beta,
                       float* running_mean, float* running_var,
                       float* scale, float* shift, float* mean_out, float* invstd_out,
                       int C, int groups, double count, float eps, float momentum, void* stream);
 /* (dscale,dshift)[g][c] -> dgamma[c], dbeta[c] and dstats[g][2][c] (gradient w.r.t. S1, S2; zero in eval). */
-int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gamma,
+int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, int nrep, const float* gamma,
                           const float* mean, const float* invstd,
                           float* dgamma, float* dbeta, double* dstats, int stats_ld, int accumulate_dstats,
                           int C, int groups, double count, int train, void* stream);
@@ -148,10 +150,13 @@ int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const void* res, 
                      const float* scale, const float* shift, long npix, int C, int groups, int act,
                      int dtype, void* stream);
 /* act: 0 none, 1 ReLU, 2 sigmoid, 4 sigmoid with x holding the sigmoid OUTPUT.
+ * dscale/dshift are replicated [nrep][groups][C] (see stats_nrep above; sdhip_bn_finalize_bwd sums them).
  * gx (+)= gy*act'*scale (if gx != NULL; += when accumulate != 0); dscale = sum gy*act'*x, dshift = sum gy*act' (if non-NULL; zeroed here). */
 int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
-                         const float* scale, const float* shift, float* dscale, float* dshift,
+                         const float* scale, const float* shift, float* dscale, float* dshift, int nrep,
                          long npix, int C, int groups, int act, int accumulate, int dtype, void* stream);
+/* out[row][c] += sum_r ws[r][row][c] over the 2*groups statistics rows (folds conv-epilogue replicas into a slab). */
+int sdhip_stats_replica_sum(const double* ws, double* out, int nrep, int groups, int C, int ldw, int ldo, void* stream);
 /* gout = gin + dstats[g][0][c] + 2*x*dstats[g][1][c]: the gradient that flows through the batch statistics. */
 int sdhip_stats_fix(const void* gin, int ldgi, const void* x, int ldx, void* gout, int ldgo,
                     const double* dstats, int stats_ld, long npix, int C, int groups, int dtype, void* stream);

@@ -71,7 +71,7 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* gy, int ldg, const T* __restrict__ x, int ldx,
                                                              T* gx, int ldgx,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             float* __restrict__ dscale, float* __restrict__ dshift,
+                                                             float* __restrict__ dscale, float* __restrict__ dshift, int nrep,
                                                              int C, long npix_g, int act, int accumulate, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
   __shared__ float red[2][256 * (VEC ? Chunk<T>::N : 1)];
@@ -124,8 +124,9 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* gy, int ld
     for (int e = 0; e < N; ++e) {
       float s1 = 0.f, s2 = 0.f;
       for (int r = 0; r < rg.ty; ++r) { s1 += red[0][(r * rg.tx + tx) * N + e]; s2 += red[1][(r * rg.tx + tx) * N + e]; }
-      atomicAdd(dscale + g * C + c0 + e, s1);
-      atomicAdd(dshift + g * C + c0 + e, s2);
+      const long rep = (long)(blockIdx.x % nrep) * gridDim.z * C;   // replica r of [nrep][G][C]
+      atomicAdd(dscale + rep + g * C + c0 + e, s1);
+      atomicAdd(dshift + rep + g * C + c0 + e, s2);
     }
   }
 }
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const T* gin, int ldgi, 
 
 // S[g][0][c] += sum x, S[g][1][c] += sum x^2  (f64 atomics)
 template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, int ldx, double* __restrict__ S, int ldc,
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, int ldx, double* __restrict__ S, int ldc, int nrep,
                                                             int C, long npix_g, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
   __shared__ float red[2][256 * (VEC ? Chunk<T>::N : 1)];
@@ -184,15 +185,16 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
     for (int e = 0; e < N; ++e) {
       double s1 = 0., s2 = 0.;
       for (int r = 0; r < rg.ty; ++r) { s1 += red[0][(r * rg.tx + tx) * N + e]; s2 += red[1][(r * rg.tx + tx) * N + e]; }
-      atomicAdd(S + ((long)g * 2 + 0) * ldc + c0 + e, s1);
-      atomicAdd(S + ((long)g * 2 + 1) * ldc + c0 + e, s2);
+      double* Sr = S + (long)(blockIdx.x % nrep) * gridDim.z * 2 * ldc;   // replica r of [nrep][G][2][ldc]
+      atomicAdd(Sr + ((long)g * 2 + 0) * ldc + c0 + e, s1);
+      atomicAdd(Sr + ((long)g * 2 + 1) * ldc + c0 + e, s2);
     }
   }
 }
 
 // ---- per-channel finalize (tiny) ------------------------------------------------
 // train: S -> mean, invstd, scale, shift, running stats (groups applied in order)
-__global__ void bn_finalize_kernel(const double* __restrict__ S, int ldc, const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ void bn_finalize_kernel(const double* __restrict__ S, int ldc, int nrep, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rmean, float* __restrict__ rvar,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, int C, int G, double count, float eps, float momentum) {
@@ -210,8 +212,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ S, int ldc, const 
   }
   float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
   for (int g = 0; g < G; ++g) {
-    const double mu = S[((long)g * 2 + 0) * ldc + c] / count;
-    double var = S[((long)g * 2 + 1) * ldc + c] / count - mu * mu;
+    double s1 = 0., s2 = 0.;
+    for (int r = 0; r < nrep; ++r) {
+      const double* Sr = S + (long)r * G * 2 * ldc;
+      s1 += Sr[((long)g * 2 + 0) * ldc + c];
+      s2 += Sr[((long)g * 2 + 1) * ldc + c];
+    }
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
     if (var < 0.) var = 0.;
     const float inv = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gm * inv;
@@ -227,7 +235,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ S, int ldc, const 
 }
 
 // (dscale, dshift)[G][C] -> dgamma[C], dbeta[C] (summed over groups), dS[G][2][C]
-__global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
+__global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift, int nrep,
                                        const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, double* __restrict__ dS, int ldc, int acc_ds,
                                        int C, int G, double count, int train) {
@@ -236,7 +244,8 @@ __global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const f
   const float gm = gamma ? gamma[c] : 1.f;
   float dg = 0.f, db = 0.f;
   for (int g = 0; g < G; ++g) {
-    const float ds = dscale[g * C + c], dh = dshift[g * C + c];
+    float ds = 0.f, dh = 0.f;
+    for (int r = 0; r < nrep; ++r) { ds += dscale[((long)r * G + g) * C + c]; dh += dshift[((long)r * G + g) * C + c]; }
     const float mu = mean[g * C + c], inv = invstd[g * C + c];
     const float t = ds - mu * dh;       // d/d(gamma*invstd) collected
     dg += inv * t;
@@ -290,6 +299,26 @@ int check_rows(const char* who, long npix, int C, int G, int dtype) {
 
 }  // namespace
 
+// out[row*ldo + c] += sum_r ws[r*rep_stride + row*ldw + c]   (rows = 2*groups statistics rows)
+__global__ void replica_sum_kernel(const double* __restrict__ ws, double* __restrict__ out, int nrep, long rep_stride,
+                                   int rows, int C, int ldw, int ldo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const int row = i / C, c = i - row * C;
+  double s = 0.;
+  for (int r = 0; r < nrep; ++r) s += ws[(long)r * rep_stride + (long)row * ldw + c];
+  out[(long)row * ldo + c] += s;
+}
+
+extern "C" int sdhip_stats_replica_sum(const double* ws, double* out, int nrep, int groups, int C, int ldw, int ldo, void* stream) {
+  SDHIP_CHECK_ARG(ws && out && nrep >= 1 && groups >= 1 && C > 0 && ldw >= C && ldo >= C, "stats_replica_sum: bad arguments");
+  const int rows = 2 * groups;
+  hipLaunchKernelGGL(replica_sum_kernel, dim3(sdhip_cdiv((long)rows * C, 256)), dim3(256), 0, (hipStream_t)stream, ws, out, nrep,
+                     (long)rows * ldw, rows, C, ldw, ldo);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
 extern "C" int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const void* res, int ldr,
                                 const float* scale, const float* shift, long npix, int C, int groups, int act,
                                 int dtype, void* stream) {
@@ -315,19 +344,20 @@ extern "C" int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const 
 }
 
 extern "C" int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
-                                    const float* scale, const float* shift, float* dscale, float* dshift,
+                                    const float* scale, const float* shift, float* dscale, float* dshift, int nrep,
                                     long npix, int C, int groups, int act, int accumulate, int dtype, void* stream) {
+  if (nrep < 1) nrep = 1;
   const int G = groups;
   if (int rc = check_rows("affine_act_bwd", npix, C, G, dtype)) return rc;
   SDHIP_CHECK_ARG(gy && x && ldg >= C && ldx >= C && (!gx || ldgx >= C), "affine_act_bwd: bad pointers/strides");
   SDHIP_CHECK_ARG((dscale == nullptr) == (dshift == nullptr), "affine_act_bwd: dscale/dshift must come together");
   hipStream_t s = (hipStream_t)stream;
   if (dscale) {
-    if (hipMemsetAsync(dscale, 0, sizeof(float) * (size_t)G * C, s) != hipSuccess ||
-        hipMemsetAsync(dshift, 0, sizeof(float) * (size_t)G * C, s) != hipSuccess)
+    if (hipMemsetAsync(dscale, 0, sizeof(float) * (size_t)nrep * G * C, s) != hipSuccess ||
+        hipMemsetAsync(dshift, 0, sizeof(float) * (size_t)nrep * G * C, s) != hipSuccess)
       SDHIP_FAIL(SDHIP_ERR_LAUNCH, "affine_act_bwd: memset failed");
   }
-#define ARGS(T) (const T*)gy, ldg, (const T*)x, ldx, (T*)gx, ldgx, scale, shift, dscale, dshift, C, npix / G, act, accumulate
+#define ARGS(T) (const T*)gy, ldg, (const T*)x, ldx, (T*)gx, ldgx, scale, shift, dscale, dshift, nrep, C, npix / G, act, accumulate
   if (dtype == SDHIP_F32) {
     const bool v = vec_rows<float>(C, {ldg, ldx, gx ? ldgx : 0}, {gy, x, gx});
     Plan pl = plan(v ? C / 4 : C, npix / G, G);
@@ -368,18 +398,19 @@ extern "C" int sdhip_stats_fix(const void* gin, int ldgi, const void* x, int ldx
   return SDHIP_OK;
 }
 
-extern "C" int sdhip_channel_stats(const void* x, int ldx, double* stats, int ldc, long npix, int C, int groups,
+extern "C" int sdhip_channel_stats(const void* x, int ldx, double* stats, int ldc, int nrep, long npix, int C, int groups,
                                    int zero_first, int dtype, void* stream) {
   if (ldc <= 0) ldc = C;
+  if (nrep < 1) nrep = 1;
   const int G = groups;
   if (int rc = check_rows("channel_stats", npix, C, G, dtype)) return rc;
   SDHIP_CHECK_ARG(x && stats && ldx >= C, "channel_stats: bad pointers/strides");
   hipStream_t s = (hipStream_t)stream;
   if (zero_first) {
-    if (hipMemset2DAsync(stats, sizeof(double) * (size_t)ldc, 0, sizeof(double) * (size_t)C, 2 * (size_t)G, s) != hipSuccess)
+    if (hipMemset2DAsync(stats, sizeof(double) * (size_t)ldc, 0, sizeof(double) * (size_t)C, 2 * (size_t)G * nrep, s) != hipSuccess)
       SDHIP_FAIL(SDHIP_ERR_LAUNCH, "channel_stats: memset failed");
   }
-#define ARGS(T) (const T*)x, ldx, stats, ldc, C, npix / G
+#define ARGS(T) (const T*)x, ldx, stats, ldc, nrep, C, npix / G
   if (dtype == SDHIP_F32) {
     const bool v = vec_rows<float>(C, {ldx}, {x});
     Plan pl = plan(v ? C / 4 : C, npix / G, G);
@@ -396,26 +427,26 @@ extern "C" int sdhip_channel_stats(const void* x, int ldx, double* stats, int ld
   return SDHIP_OK;
 }
 
-extern "C" int sdhip_bn_finalize(const double* stats, int ldc, const float* gamma, const float* beta,
+extern "C" int sdhip_bn_finalize(const double* stats, int ldc, int nrep, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var,
                                  float* scale, float* shift, float* mean_out, float* invstd_out,
                                  int C, int groups, double count, float eps, float momentum, void* stream) {
   SDHIP_CHECK_ARG(C > 0 && groups >= 1 && scale && shift, "bn_finalize: bad arguments");
   SDHIP_CHECK_ARG(stats || (running_mean && running_var), "bn_finalize: eval mode needs running statistics");
   SDHIP_CHECK_ARG(!stats || (mean_out && invstd_out && count >= 1.), "bn_finalize: train mode needs mean/invstd outputs and a count");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sdhip_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, ldc > 0 ? ldc : C, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sdhip_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, ldc > 0 ? ldc : C, nrep > 0 ? nrep : 1, gamma, beta,
                      running_mean, running_var, scale, shift, mean_out, invstd_out, C, groups, count, eps, momentum);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }
 
-extern "C" int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gamma,
+extern "C" int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, int nrep, const float* gamma,
                                      const float* mean, const float* invstd,
                                      float* dgamma, float* dbeta, double* dstats, int ldc, int accumulate_dstats,
                                      int C, int groups, double count, int train, void* stream) {
   SDHIP_CHECK_ARG(C > 0 && groups >= 1 && dscale && dshift && mean && invstd, "bn_finalize_bwd: bad arguments");
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(sdhip_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, dscale, dshift,
-                     gamma, mean, invstd, dgamma, dbeta, dstats, ldc > 0 ? ldc : C, accumulate_dstats, C, groups, count, train);
+                     nrep > 0 ? nrep : 1, gamma, mean, invstd, dgamma, dbeta, dstats, ldc > 0 ? ldc : C, accumulate_dstats, C, groups, count, train);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }

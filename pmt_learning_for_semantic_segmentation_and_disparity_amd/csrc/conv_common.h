@@ -43,6 +43,76 @@ struct ConvGeom {
   int kh, kw, stride, dil, pad_t, pad_l;
 };
 
+// Stage one input tile (npx = IH*IW pixels, `1<<sh` 16-byte chunks per pixel of channel chunk q) into LDS with
+// the fused prologue.  Loads are issued NB at a time before any LDS store so that NB global loads are in flight
+// per lane (a load->store->load chain would expose the full HBM latency once per chunk).
+struct StageSrc {
+  const void* base;        // first pixel of the image
+  int H, W, ld, C;         // image extent, pixel stride, channels
+  int h0, w0;              // image coordinates of tile pixel (0,0)
+  int IH, IW;              // tile extent
+  const float* scale;      // per-channel prologue (already offset to the statistics group) or nullptr
+  const float* shift;
+  int relu, vec;
+};
+
+template <typename T, int NB>
+__device__ __forceinline__ void stage_tile(unsigned char* lds, const StageSrc& s, int q, int sh, int tid) {
+  constexpr int V = Chunk<T>::N;
+  constexpr int CK = 8 * V;
+  const int total = (s.IH * s.IW) << sh;
+  const T* xb = (const T*)s.base;
+  for (int i0 = tid; i0 < total; i0 += 256 * NB) {
+    u32x4 raw[NB];
+    int ch[NB], off[NB];
+    bool in[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int i = i0 + j * 256;
+      const int pix = i >> sh, c = i & ((1 << sh) - 1);
+      const int ih = pix / s.IW, iw = pix - ih * s.IW;
+      const int gh = s.h0 + ih, gw = s.w0 + iw;
+      ch[j] = q * CK + c * V;
+      off[j] = lds_off(pix, c);
+      in[j] = i < total && gh >= 0 && gh < s.H && gw >= 0 && gw < s.W && ch[j] < s.C;
+      raw[j] = u32x4{0u, 0u, 0u, 0u};
+      if (in[j]) {
+        const T* src = xb + ((long)gh * s.W + gw) * s.ld + ch[j];
+        if (s.vec) {
+          raw[j] = *reinterpret_cast<const u32x4*>(src);
+        } else {
+          float f[V];
+#pragma unroll
+          for (int e = 0; e < V; ++e) f[e] = (ch[j] + e < s.C) ? Elem<T>::ld(src + e) : 0.f;
+          raw[j] = Chunk<T>::pack(f);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (i0 + j * 256 < total) {
+        if (s.scale && in[j]) {
+          float f[V];
+          Chunk<T>::unpack(raw[j], f);
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            if (ch[j] + e < s.C) {
+              const float v = fmaf(f[e], s.scale[ch[j] + e], s.shift[ch[j] + e]);
+              f[e] = s.relu ? fmaxf(v, 0.f) : v;
+            }
+          }
+          raw[j] = Chunk<T>::pack(f);
+        }
+        *reinterpret_cast<u32x4*>(lds + off[j]) = raw[j];
+      }
+    }
+  }
+}
+
+// number of statistics replicas the conv epilogue / reduction kernels spread their atomics over: thousands of
+// workgroups adding into ONE 256-byte line serialise at the memory side (~25 ns per wave-instruction).
+#define SDHIP_NREP 32
+
 // host-side: channels per 128-byte row
 static inline int conv_ck(int dtype) { return dtype == SDHIP_BF16 ? 64 : 32; }
 static inline int conv_esize(int dtype) { return dtype == SDHIP_BF16 ? 2 : 4; }

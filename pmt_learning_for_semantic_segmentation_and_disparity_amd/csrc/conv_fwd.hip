@@ -24,7 +24,8 @@ struct FwdArgs {
   ConvGeom g;
   int Cin, ldx, Cout, Mpad, ldy;
   int in_relu, groups, act, accumulate;
-  int tg, vec_in, vec_out, stats_ld;
+  int tg, vec_in, vec_out, stats_ld, nrep;
+  long rep_stride;
 };
 
 template <typename T, int TH, int TW, int BN>
@@ -77,52 +78,33 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
     const int sh = nks == 2 ? 3 : 2;                  // chunks per row that carry data: 8 or 4
     __syncthreads();                                  // previous chunk's fragments are consumed
     // ---- stage the halo tile (global -> LDS, fused prologue) ----
-    for (int i = tid; i < ((IH * IW) << sh); i += 256) {
-      const int pix = i >> sh, c = i & ((1 << sh) - 1);
-      const int ih = pix / IW, iw = pix - ih * IW;
-      const int gh = ih0 + ih, gw = iw0 + iw;
-      const int ch0 = q * CK + c * V;
-      float f[V];
-#pragma unroll
-      for (int e = 0; e < V; ++e) f[e] = 0.f;
-      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
-      const bool inside = gh >= 0 && gh < g.H && gw >= 0 && gw < g.W && ch0 < p.Cin;
-      if (inside) {
-        const T* src = xb + ((long)gh * g.W + gw) * p.ldx + ch0;
-        if (p.vec_in) {
-          raw = *reinterpret_cast<const u32x4*>(src);
-          if (p.in_scale) Chunk<T>::unpack(raw, f);
-        } else {
-#pragma unroll
-          for (int e = 0; e < V; ++e) if (ch0 + e < p.Cin) f[e] = Elem<T>::ld(src + e);
-        }
-        if (p.in_scale) {
-          const float* sc = p.in_scale + grp * p.Cin + ch0;
-          const float* sf = p.in_shift + grp * p.Cin + ch0;
-#pragma unroll
-          for (int e = 0; e < V; ++e) {
-            if (ch0 + e < p.Cin) {
-              float v = fmaf(f[e], sc[e], sf[e]);
-              f[e] = p.in_relu ? fmaxf(v, 0.f) : v;
-            }
-          }
-          raw = Chunk<T>::pack(f);
-        } else if (!p.vec_in) {
-          raw = Chunk<T>::pack(f);
-        }
-      }
-      *reinterpret_cast<u32x4*>(halo + lds_off(pix, c)) = raw;
+    {
+      StageSrc ss;
+      ss.base = xb; ss.H = g.H; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin; ss.h0 = ih0; ss.w0 = iw0; ss.IH = IH; ss.IW = IW;
+      ss.scale = p.in_scale ? p.in_scale + grp * p.Cin : nullptr;
+      ss.shift = p.in_scale ? p.in_shift + grp * p.Cin : nullptr;
+      ss.relu = p.in_relu; ss.vec = p.vec_in;
+      stage_tile<T, 4>(halo, ss, q, sh, tid);
     }
 
     for (int t0 = 0; t0 < Tn; t0 += p.tg) {
       const int nt = min(p.tg, Tn - t0);
       if (t0 > 0) __syncthreads();  // previous tap group's weights are consumed
       // ---- stage the weights of taps [t0, t0+nt) for this channel chunk ----
-      for (int i = tid; i < ((nt * mvalid) << sh); i += 256) {
-        const int row = i >> sh, c = i & ((1 << sh) - 1);
-        const int tl = row / mvalid, m = row - tl * mvalid;
-        const T* src = wpk + (((long)(q * Tn + t0 + tl) * p.Mpad + n0 + m) * CK + c * V);
-        *reinterpret_cast<u32x4*>(wl + lds_off(tl * BN + m, c)) = *reinterpret_cast<const u32x4*>(src);
+      const int wtotal = (nt * mvalid) << sh;
+      for (int i0 = tid; i0 < wtotal; i0 += 256 * 4) {
+        u32x4 raw[4]; int off[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = i0 + j * 256;
+          const int row = i >> sh, c = i & ((1 << sh) - 1);
+          const int tl = row / mvalid, m = row - tl * mvalid;
+          off[j] = lds_off(tl * BN + m, c);
+          if (i < wtotal) raw[j] = *reinterpret_cast<const u32x4*>(wpk + (((long)(q * Tn + t0 + tl) * p.Mpad + n0 + m) * CK + c * V));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (i0 + j * 256 < wtotal) *reinterpret_cast<u32x4*>(wl + off[j]) = raw[j];
       }
       __syncthreads();
       // ---- MFMA over the taps of this group ----
@@ -236,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
       if (n0 + m < p.Cout) {
         const float tot = red[(0 * 2 + which) * BN + m] + red[(1 * 2 + which) * BN + m] +
                           red[(2 * 2 + which) * BN + m] + red[(3 * 2 + which) * BN + m];
-        atomicAdd(p.stats + ((long)grp * 2 + which) * p.stats_ld + n0 + m, (double)tot);
+        atomicAdd(p.stats + (long)((blockIdx.x + blockIdx.z) % p.nrep) * p.rep_stride + ((long)grp * 2 + which) * p.stats_ld + n0 + m, (double)tot);
       }
     }
   }
@@ -279,7 +261,7 @@ size_t lds_need(const ConvGeom& g, int th, int tw, int rows_per_tap, int tg) {
 
 extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                                 const float* bias, const float* in_scale, const float* in_shift,
-                                double* stats, int stats_ld,
+                                double* stats, int stats_ld, int stats_nrep,
                                 int B, int H, int W, int Cin, int ldx,
                                 int Ho, int Wo, int Cout, int ldy,
                                 int kh, int kw, int stride, int dil, int pad_t, int pad_l,
@@ -301,6 +283,8 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   a.Cin = Cin; a.ldx = ldx; a.Cout = Cout; a.Mpad = (Cout + 15) & ~15; a.ldy = ldy;
   a.in_relu = in_relu; a.groups = groups; a.act = act; a.accumulate = accumulate;
   a.stats_ld = stats_ld > 0 ? stats_ld : Cout;
+  a.nrep = stats_nrep > 0 ? stats_nrep : 1;
+  a.rep_stride = (long)groups * 2 * a.stats_ld;
   a.vec_in = (Cin % V == 0) && (ldx % V == 0) && (((uintptr_t)x & 15) == 0);
   a.vec_out = (ldy % 4 == 0) && (((uintptr_t)y % (4 * es)) == 0);
   const int bn = a.Mpad > 64 ? 128 : (a.Mpad > 32 ? 64 : (a.Mpad > 16 ? 32 : 16));

@@ -101,59 +101,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
     const T* yb = (const T*)p.dy + (long)b * g.Ho * g.Wo * p.lddy;
     __syncthreads();  // previous tile's fragments are consumed
     // ---- stage the X halo tile of channel chunk q (same image as the forward kernel) ----
-    for (int i = tid; i < ((IH * IW) << shx); i += 256) {
-      const int pix = i >> shx, c = i & ((1 << shx) - 1);
-      const int ih = pix / IW, iw = pix - ih * IW;
-      const int gh = ih0 + ih, gw = iw0 + iw;
-      const int ch0 = q * CK + c * V;
-      float f[V];
-#pragma unroll
-      for (int e = 0; e < V; ++e) f[e] = 0.f;
-      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
-      if (gh >= 0 && gh < g.H && gw >= 0 && gw < g.W && ch0 < p.Cin) {
-        const T* src = xb + ((long)gh * g.W + gw) * p.ldx + ch0;
-        if (p.vec_x) {
-          raw = *reinterpret_cast<const u32x4*>(src);
-          if (p.in_scale) Chunk<T>::unpack(raw, f);
-        } else {
-#pragma unroll
-          for (int e = 0; e < V; ++e) if (ch0 + e < p.Cin) f[e] = Elem<T>::ld(src + e);
-        }
-        if (p.in_scale) {
-          const float* sc = p.in_scale + grp * p.Cin + ch0;
-          const float* sf = p.in_shift + grp * p.Cin + ch0;
-#pragma unroll
-          for (int e = 0; e < V; ++e)
-            if (ch0 + e < p.Cin) {
-              const float v = fmaf(f[e], sc[e], sf[e]);
-              f[e] = p.in_relu ? fmaxf(v, 0.f) : v;
-            }
-          raw = Chunk<T>::pack(f);
-        } else if (!p.vec_x) {
-          raw = Chunk<T>::pack(f);
-        }
-      }
-      *reinterpret_cast<u32x4*>(halo + lds_off(pix, c)) = raw;
+    {
+      StageSrc ss;
+      ss.base = xb; ss.H = g.H; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin; ss.h0 = ih0; ss.w0 = iw0; ss.IH = IH; ss.IW = IW;
+      ss.scale = p.in_scale ? p.in_scale + grp * p.Cin : nullptr;
+      ss.shift = p.in_scale ? p.in_shift + grp * p.Cin : nullptr;
+      ss.relu = p.in_relu; ss.vec = p.vec_x;
+      stage_tile<T, 4>(halo, ss, q, shx, tid);
     }
-    // ---- stage the dY tile of output-channel block mb ----
-    for (int i = tid; i < ((TH * TW) << shy); i += 256) {
-      const int pix = i >> shy, c = i & ((1 << shy) - 1);
-      const int orow = pix / TW, ocol = pix - orow * TW;
-      const int oh = oh0 + orow, ow = ow0 + ocol;
-      const int ch0 = m0 + c * V;
-      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
-      if (oh < g.Ho && ow < g.Wo && ch0 < p.Cout) {
-        const T* src = yb + ((long)oh * g.Wo + ow) * p.lddy + ch0;
-        if (p.vec_dy) {
-          raw = *reinterpret_cast<const u32x4*>(src);
-        } else {
-          float f[V];
-#pragma unroll
-          for (int e = 0; e < V; ++e) f[e] = (ch0 + e < p.Cout) ? Elem<T>::ld(src + e) : 0.f;
-          raw = Chunk<T>::pack(f);
-        }
-      }
-      *reinterpret_cast<u32x4*>(ytile + lds_off(pix, c)) = raw;
+    // ---- stage the dY tile of output-channel block mb (a TH x TW tile with no halo; channels offset by m0) ----
+    {
+      StageSrc ss;
+      ss.base = yb + m0; ss.H = g.Ho; ss.W = g.Wo; ss.ld = p.lddy; ss.C = p.Cout - m0; ss.h0 = oh0; ss.w0 = ow0; ss.IH = TH; ss.IW = TW;
+      ss.scale = nullptr; ss.shift = nullptr; ss.relu = 0;
+      ss.vec = p.vec_dy && ((m0 * (int)sizeof(T)) % 16 == 0);
+      stage_tile<T, 4>(ytile, ss, 0, shy, tid);
     }
     __syncthreads();
 

@@ -26,22 +26,11 @@ from . import ops
 from ._lib import call, dtype_code, ptr, stream_ptr
 
 
-def _finalize(stats, bn, count, groups, training):
-    """scale, shift, mean, invstd of one BatchNorm2d over (a slice of) a statistics slab."""
-    C = bn.num_features
-    dev = bn.weight.device
-    out = [torch.empty((groups, C), dtype=torch.float32, device=dev) for _ in range(4)]
-    if training:
-        mom = 0.1 if bn.momentum is None else bn.momentum
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += groups
-        call("sdhip_bn_finalize", ptr(stats), stats.stride(1), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
-             ptr(bn.running_var), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, groups, float(count),
-             float(bn.eps), float(mom), stream_ptr())
-    else:
-        call("sdhip_bn_finalize", None, 0, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
-             ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, groups, float(count), float(bn.eps), 0.0, stream_ptr())
-    return out
+NREP = ops.NREP
+
+
+def _finalize(stats, nrep, bn, count, groups, training):
+    return ops._bn_finalize(stats if training else None, nrep, bn, count, groups)
 
 
 def _wgrad(x, ldx, dy, lddy, weight, B, H, W, Cin, Cout, k, pad, in_scale, in_shift, groups, dt):
@@ -75,22 +64,27 @@ class _DenseBlockFn(torch.autograd.Function):
         xv, ldx = ops.nhwc_view(x0)
         call("sdhip_affine_act", ptr(xv), ldx, ptr(slab), Ct, None, 0, None, None, npix, C0, 1, 0, dt, stream_ptr())
         S = torch.zeros((groups, 2, Ct), dtype=torch.float64, device=dev)
-        if training:
-            call("sdhip_channel_stats", ptr(slab), Ct, ptr(S), Ct, npix, C0, groups, 0, dt, stream_ptr())
+        if training:   # statistics of the incoming features (the producer was a pool, not a conv epilogue)
+            ws0 = torch.empty((NREP, groups, 2, C0), dtype=torch.float64, device=dev)
+            call("sdhip_channel_stats", ptr(slab), Ct, ptr(ws0), C0, NREP, npix, C0, groups, 1, dt, stream_ptr())
+            call("sdhip_stats_replica_sum", ptr(ws0), ptr(S), NREP, groups, C0, C0, Ct, stream_ptr())
         saved = []
         for li, layer in enumerate(layers):
             Cin = C0 + li * growth
-            sc1, sh1, mu1, iv1 = _finalize(S[:, :, :Cin], layer.norm1, count, groups, training)
+            sc1, sh1, mu1, iv1 = _finalize(S[:, :, :Cin], 1, layer.norm1, count, groups, training)
             w1 = ops.packed_weight(layer.conv1.weight, 'conv', 'fwd', dtype)
             y1 = ops.empty_nhwc(B, mid, H, W, dtype, dev)
-            S2 = torch.zeros((groups, 2, mid), dtype=torch.float64, device=dev) if training else None
+            S2 = torch.zeros((NREP, groups, 2, mid), dtype=torch.float64, device=dev) if training else None
             ops._conv_launch(slab, Ct, w1, y1, mid, None, sc1, sh1, S2, B, H, W, Cin, H, W, mid, 1, 1, 1, 1, 0, 0,
-                             True, groups, 0, False)
-            sc2, sh2, mu2, iv2 = _finalize(S2, layer.norm2, count, groups, training)
+                             True, groups, 0, False, NREP)
+            sc2, sh2, mu2, iv2 = _finalize(S2, NREP, layer.norm2, count, groups, training)
             w2 = ops.packed_weight(layer.conv2.weight, 'conv', 'fwd', dtype)
-            ops._conv_launch(y1, mid, w2, slab[:, Cin:Cin + growth], Ct, None, sc2, sh2,
-                             S[:, :, Cin:Cin + growth] if training else None, B, H, W, mid, H, W, growth, 3, 3, 1, 1, 1, 1,
-                             True, groups, 0, False)
+            S3 = torch.zeros((NREP, groups, 2, growth), dtype=torch.float64, device=dev) if training else None
+            ops._conv_launch(y1, mid, w2, slab[:, Cin:Cin + growth], Ct, None, sc2, sh2, S3, B, H, W, mid, H, W, growth,
+                             3, 3, 1, 1, 1, 1, True, groups, 0, False, NREP)
+            if training:   # fold the replicas into this layer's slice of the slab statistics
+                call("sdhip_stats_replica_sum", ptr(S3), ptr(S[:, :, Cin:Cin + growth]), NREP, groups, growth, growth, Ct,
+                     stream_ptr())
             saved.append((y1, sc1, sh1, mu1, iv1, sc2, sh2, mu2, iv2))
         ctx.block, ctx.groups, ctx.saved, ctx.slab = block, groups, saved, slab
         ctx.geom = (B, C0, H, W, growth, mid, Ct, training, count)
@@ -120,7 +114,7 @@ class _DenseBlockFn(torch.autograd.Function):
             # (1) total gradient of this layer's 32 output channels (all consumers are already accumulated)
             dy2 = ops.empty_nhwc(B, growth, H, W, dtype, dev)
             call("sdhip_stats_fix", ptr(sl_g), Ct, ptr(sl_x), Ct, ptr(dy2), growth, ptr(dS[:, :, Cin:Cin + growth]), Ct,
-                 npix, growth, groups, dt, st)
+                 npix, growth, groups, dt, st)   # dS is all zero in eval mode
             # (2) conv2 (3x3): data gradient w.r.t. relu(norm2(y1)), weight gradient
             wd2 = ops.packed_weight(layer.conv2.weight, 'conv', 'dgrad', dtype)
             gp2 = ops.empty_nhwc(B, mid, H, W, dtype, dev)
@@ -128,27 +122,20 @@ class _DenseBlockFn(torch.autograd.Function):
                              False, 1, 0, False)
             gw2 = _wgrad(y1, mid, dy2, growth, layer.conv2.weight, B, H, W, mid, growth, 3, 1, sc2, sh2, groups, dt)
             # (3) through relu + norm2's affine, (4) norm2's statistics, (5) into y1
-            dsc2 = torch.empty_like(sc2); dsh2 = torch.empty_like(sh2)
-            call("sdhip_affine_act_bwd", ptr(gp2), mid, ptr(y1), mid, ptr(gp2), mid, ptr(sc2), ptr(sh2), ptr(dsc2), ptr(dsh2),
-                 npix, mid, groups, 1, 0, dt, st)
-            dg2 = torch.empty(mid, dtype=torch.float32, device=dev); db2 = torch.empty(mid, dtype=torch.float32, device=dev)
-            dS2 = torch.empty((groups, 2, mid), dtype=torch.float64, device=dev)
-            call("sdhip_bn_finalize_bwd", ptr(dsc2), ptr(dsh2), ptr(layer.norm2.weight), ptr(mu2), ptr(iv2), ptr(dg2), ptr(db2),
-                 ptr(dS2), mid, 0, mid, groups, float(count), int(training), st)
-            call("sdhip_stats_fix", ptr(gp2), mid, ptr(y1), mid, ptr(gp2), mid, ptr(dS2), mid, npix, mid, groups, dt, st)
+            dg2, db2, dS2 = ops._bn_backward(gp2, mid, y1, mid, gp2, mid, sc2, sh2, mu2, iv2, layer.norm2.weight, npix, mid,
+                                             groups, 1, count, training, dt)
+            if training:
+                call("sdhip_stats_fix", ptr(gp2), mid, ptr(y1), mid, ptr(gp2), mid, ptr(dS2), mid, npix, mid, groups, dt, st)
             # (6) conv1 (1x1): data gradient w.r.t. relu(norm1(slab[:Cin])), weight gradient
             wd1 = ops.packed_weight(layer.conv1.weight, 'conv', 'dgrad', dtype)
             gp1 = ops.empty_nhwc(B, Cin, H, W, dtype, dev)
             ops._conv_launch(gp2, mid, wd1, gp1, Cin, None, None, None, None, B, H, W, mid, H, W, Cin, 1, 1, 1, 1, 0, 0,
                              False, 1, 0, False)
             gw1 = _wgrad(slab, Ct, gp2, mid, layer.conv1.weight, B, H, W, Cin, mid, 1, 0, sc1, sh1, groups, dt)
-            # (7) through relu + norm1's affine, accumulated into the slab gradient; (8) norm1's statistics
-            dsc1 = torch.empty_like(sc1); dsh1 = torch.empty_like(sh1)
-            call("sdhip_affine_act_bwd", ptr(gp1), Cin, ptr(slab), Ct, ptr(g_slab), Ct, ptr(sc1), ptr(sh1), ptr(dsc1), ptr(dsh1),
-                 npix, Cin, groups, 1, 1, dt, st)
-            dg1 = torch.empty(Cin, dtype=torch.float32, device=dev); db1 = torch.empty(Cin, dtype=torch.float32, device=dev)
-            call("sdhip_bn_finalize_bwd", ptr(dsc1), ptr(dsh1), ptr(layer.norm1.weight), ptr(mu1), ptr(iv1), ptr(dg1), ptr(db1),
-                 ptr(dS), Ct, 1, Cin, groups, float(count), int(training), st)
+            # (7) through relu + norm1's affine, accumulated into the slab gradient; (8) norm1's statistics -> dS
+            dg1, db1, _ = ops._bn_backward(gp1, Cin, slab, Ct, g_slab, Ct, sc1, sh1, mu1, iv1, layer.norm1.weight, npix, Cin,
+                                           groups, 1, count, training, dt, accumulate_gx=True, dstats=dS[:, :, :Cin],
+                                           accumulate_dstats=True)
             grads.append((dg1, db1, gw1, dg2, db2, gw2))
         gx0 = ops.empty_nhwc(B, C0, H, W, dtype, dev)
         call("sdhip_stats_fix", ptr(g_slab), Ct, ptr(slab), Ct, ptr(gx0), C0, ptr(dS), Ct, npix, C0, groups, dt, st)
@@ -156,6 +143,51 @@ class _DenseBlockFn(torch.autograd.Function):
         for g6 in reversed(grads):
             flat.extend(g6)
         return (gx0, None, None) + tuple(flat)
+
+
+class _Stem(torch.autograd.Function):
+    """conv0 (7x7 / 2) -> tap 0 (raw) and relu(norm0(.)): both outputs are used (models/densenet.py:222-225)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bn, groups):
+        B, Cin, H, W = x.shape
+        xv, ldx = ops.nhwc_view(x)
+        spec = ops.conv_spec(x, weight, 'conv', 2, 1, 3)
+        Cout = weight.shape[0]
+        wp = ops.packed_weight(weight, 'conv', 'fwd', x.dtype)
+        c0 = ops.empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
+        train = bn.training
+        ws = torch.zeros((NREP, groups, 2, Cout), dtype=torch.float64, device=x.device) if train else None
+        ops._conv_launch(xv, ldx, wp, c0, Cout, None, None, None, ws, B, H, W, Cin, spec.Ho, spec.Wo, Cout, 7, 7, 2, 1, 3, 3,
+                         False, groups, 0, False, NREP)
+        count = (B // groups) * spec.Ho * spec.Wo
+        scale, shift, mean, invstd = ops._bn_finalize(ws, NREP, bn, count, groups)
+        f = ops.empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
+        call("sdhip_affine_act", ptr(c0), Cout, ptr(f), Cout, None, 0, ptr(scale), ptr(shift), B * spec.Ho * spec.Wo, Cout,
+             groups, 1, dtype_code(x), stream_ptr())
+        ctx.cfg = (spec, groups, ldx, count, train)
+        ctx.save_for_backward(xv, weight, gamma, c0, scale, shift, mean, invstd)
+        return c0, f
+
+    @staticmethod
+    def backward(ctx, g0, gf):
+        xv, weight, gamma, c0, scale, shift, mean, invstd = ctx.saved_tensors
+        spec, groups, ldx, count, train = ctx.cfg
+        B, Cout = c0.shape[0], c0.shape[1]
+        npix = B * spec.Ho * spec.Wo
+        dt = dtype_code(xv)
+        # gradient w.r.t. the raw conv output = tap-0 consumers + the norm0/relu branch
+        graw = ops.empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
+        gv, ldg = ops.nhwc_view(g0)
+        call("sdhip_affine_act", ptr(gv), ldg, ptr(graw), Cout, None, 0, None, None, npix, Cout, 1, 0, dt, stream_ptr())
+        fv, ldf = ops.nhwc_view(gf)
+        dgamma, dbeta, dS = ops._bn_backward(fv, ldf, c0, Cout, graw, Cout, scale, shift, mean, invstd, gamma, npix, Cout,
+                                             groups, 1, count, train, dt, accumulate_gx=True)
+        if train:
+            call("sdhip_stats_fix", ptr(graw), Cout, ptr(c0), Cout, ptr(graw), Cout, ptr(dS), Cout, npix, Cout, groups, dt,
+                 stream_ptr())
+        _, gw, _ = ops._conv_backward(spec, xv, ldx, weight, graw, Cout, None, None, False, 1, False, True, False)
+        return None, gw, dgamma, dbeta, None, None
 
 
 class _DenseLayer(nn.Module):
@@ -195,10 +227,7 @@ class _Transition(nn.Sequential):
                                      conv=nn.Conv2d(cin, cout, 1, bias=False)))
 
     def forward(self, slab, stats, groups=1):
-        B, C, H, W = slab.shape
-        scale, shift = ops.bn_scale_shift(self.norm, stats if self.norm.training else None, (B // groups) * H * W, groups)
-        return ops.conv2d(slab, self.conv.weight, None, kind='conv', padding=0, in_scale=scale, in_shift=shift,
-                          in_relu=True, groups=groups)
+        return ops.bn_conv(slab, stats, self.norm, self.conv.weight, padding=0, groups=groups)
 
 
 class DenseNet(nn.Module):
@@ -230,14 +259,9 @@ class DenseNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward(self, x, groups=1):
-        from .nn import bn_apply
-        n0 = self.features.norm0
-        if n0.training:
-            c0, st = ops.conv2d(x, self.conv0.weight, None, kind='conv', stride=2, padding=3, want_stats=True, groups=groups)
-        else:
-            c0, st = ops.conv2d(x, self.conv0.weight, None, kind='conv', stride=2, padding=3, groups=groups), None
+        c0, f = _Stem.apply(x, self.conv0.weight, self.features.norm0.weight, self.features.norm0.bias, self.features.norm0, groups)
         taps = [c0]
-        f = ops.maxpool3s2(bn_apply(n0, c0, st, act=1, groups=groups))
+        f = ops.maxpool3s2(f)
         stats = None
         for i, blk in enumerate(self.denseblock):
             if i % 2 == 0:
@@ -246,7 +270,7 @@ class DenseNet(nn.Module):
                 f = blk(f, stats, groups)
                 taps.append(f)
                 f = ops.avgpool(f, 2)
-        taps.append(bn_apply(self.norm5, f, stats, act=1, groups=groups))
+        taps.append(ops.bn_act(f, stats, self.norm5, act=1, groups=groups))
         return taps
 
 

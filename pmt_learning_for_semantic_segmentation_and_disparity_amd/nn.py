@@ -48,13 +48,6 @@ def _no_dropout(p, training):
         raise NotImplementedError("Dropout(p>0) in training mode is not on the native path yet (the shipped recipe uses p=0)")
 
 
-def bn_apply(bn, y, stats, act=0, residual=None, groups=1):
-    """BatchNorm2d (+activation, + skip add) of a raw conv output whose batch statistics rode on the conv epilogue."""
-    B, C, H, W = y.shape
-    scale, shift = ops.bn_scale_shift(bn, stats, (B // groups) * H * W, groups)
-    return ops.affine_act(y, scale, shift, residual, act, groups)
-
-
 class conv2dSame(nn.Module):
     """models/torch_model.py:236-281. `c2d` is kept as the parameter container (state_dict key `c2d.weight`)."""
 
@@ -64,11 +57,15 @@ class conv2dSame(nn.Module):
         self.c2d = nn.Conv2d(in_channel, out_channel, kernel_size, stride=stride, dilation=dilation, bias=bias)
         _he_init([self.c2d])
 
-    def run(self, x, act=0, want_stats=False, groups=1, in_scale=None, in_shift=None, in_relu=False):
+    def _geom(self):
         c = self.c2d
-        return ops.conv2d(x, c.weight, c.bias, kind='conv', stride=c.stride[0], dilation=c.dilation[0],
-                          padding='same' if self.padding == 'same' else 0, act=act, want_stats=want_stats, groups=groups,
-                          in_scale=in_scale, in_shift=in_shift, in_relu=in_relu)
+        return dict(kind='conv', stride=c.stride[0], dilation=c.dilation[0], padding='same' if self.padding == 'same' else 0)
+
+    def run(self, x, act=0):
+        return ops.conv2d(x, self.c2d.weight, self.c2d.bias, act=act, **self._geom())
+
+    def run_bn(self, x, bn, act=0, residual=None, groups=1):
+        return ops.conv_bn_act(x, self.c2d.weight, bn, act=act, residual=residual, groups=groups, **self._geom())
 
     def forward(self, x):
         return self.run(x)
@@ -83,12 +80,17 @@ class ConvTranspose2dSame(nn.Module):
         self.padding = padding
         self.ct2d = nn.ConvTranspose2d(in_channel, out_channel, kernel_size, stride=stride, dilation=dilation, bias=bias)
 
-    def run(self, x, act=0, want_stats=False, groups=1):
+    def _geom(self):
         c = self.ct2d
         if self.padding != 'same' or c.stride[0] != 1:
             raise NotImplementedError("ConvTranspose2dSame: only padding='same', stride=1 is on the native path")
-        return ops.conv2d(x, c.weight, c.bias, kind='deconv', stride=1, dilation=c.dilation[0], padding='ctsame',
-                          act=act, want_stats=want_stats, groups=groups)
+        return dict(kind='deconv', stride=1, dilation=c.dilation[0], padding='ctsame')
+
+    def run(self, x, act=0):
+        return ops.conv2d(x, self.ct2d.weight, self.ct2d.bias, act=act, **self._geom())
+
+    def run_bn(self, x, bn, act=0, residual=None, groups=1):
+        return ops.conv_bn_act(x, self.ct2d.weight, bn, act=act, residual=residual, groups=groups, **self._geom())
 
     def forward(self, x):
         return self.run(x)
@@ -107,17 +109,12 @@ class convbn(nn.Module):
         _he_init(self.modules())
 
     def fused(self, x, act=0, residual=None, groups=1):
-        """conv -> BatchNorm (batch statistics from the conv epilogue) -> activation (-> + residual), 2 launches."""
+        """conv -> BatchNorm (batch statistics from the conv epilogue) -> activation (-> + residual): one autograd node."""
         conv = self.layers[0]
         if len(self.layers) == 1:
-            y = conv.run(x, act=act, groups=groups)
-            return y if residual is None else ops.affine_act(y, None, None, residual, 0, 1)
-        bn = self.layers[1]
-        if bn.training:
-            y, stats = conv.run(x, want_stats=True, groups=groups)
-        else:
-            y, stats = conv.run(x, groups=groups), None
-        return bn_apply(bn, y, stats, act, residual, groups)
+            y = conv.run(x, act=act)
+            return y if residual is None else ops.affine_act(y, None, None, residual, 0)
+        return conv.run_bn(x, self.layers[1], act=act, residual=residual, groups=groups)
 
     def forward(self, x):
         return self.fused(x)

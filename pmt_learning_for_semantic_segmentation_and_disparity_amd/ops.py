@@ -141,84 +141,228 @@ class ConvSpec:
 
 
 def _conv_launch(x, ldx, wp, y, ldy, bias, in_scale, in_shift, stats, B, H, W, Cin, Ho, Wo, Cout,
-                 kh, kw, stride, dil, pad_t, pad_l, in_relu, groups, act, accumulate):
-    call("sdhip_conv2d_fwd", ptr(x), ptr(wp), ptr(y), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(stats),
-         stats.stride(1) if stats is not None else 0, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, stride, dil, pad_t, pad_l,
+                 kh, kw, stride, dil, pad_t, pad_l, in_relu, groups, act, accumulate, nrep=1):
+    """stats: None, or f64 [nrep][groups][2][>=Cout] (or a [groups][2][C] slice of a slab with nrep=1)."""
+    sld = stats.stride(-2) if stats is not None else 0
+    call("sdhip_conv2d_fwd", ptr(x), ptr(wp), ptr(y), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(stats), sld, nrep,
+         B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, stride, dil, pad_t, pad_l,
          int(in_relu), groups, act, int(accumulate), dtype_code(x), stream_ptr())
 
 
+NREP = _lib.NREP
+
+
+def _bn_finalize(stats, nrep, bn, count, groups):
+    """(scale, shift, mean, invstd), each f32 [groups][C]; stats None => eval mode (running statistics)."""
+    C = bn.num_features
+    dev = bn.weight.device
+    out = [torch.empty((groups, C), dtype=torch.float32, device=dev) for _ in range(4)]
+    if stats is not None:
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += groups
+        call("sdhip_bn_finalize", ptr(stats), stats.stride(-2), nrep, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+             ptr(bn.running_var), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, groups, float(count),
+             float(bn.eps), float(mom), stream_ptr())
+    else:
+        call("sdhip_bn_finalize", None, 0, 1, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+             ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, groups, float(count), float(bn.eps), 0.0, stream_ptr())
+    return out
+
+
+def _bn_backward(gy, ldg, x, ldx, gx, ldgx, scale, shift, mean, invstd, gamma, npix, C, groups, act, count, train,
+                 dt, accumulate_gx=False, dstats=None, accumulate_dstats=False):
+    """Backward of y = act(x*scale + shift) with scale/shift from batch statistics.
+    Writes gx (+)= gy*act'*scale and returns (dgamma, dbeta, dstats[groups][2][C]); the caller still has to add the
+    statistics path dstats[0] + 2*x*dstats[1] (sdhip_stats_fix) to the gradient of whatever produced x."""
+    dev = scale.device
+    dsc = torch.empty((NREP, groups, C), dtype=torch.float32, device=dev)
+    dsh = torch.empty((NREP, groups, C), dtype=torch.float32, device=dev)
+    call("sdhip_affine_act_bwd", ptr(gy), ldg, ptr(x), ldx, ptr(gx), ldgx, ptr(scale), ptr(shift), ptr(dsc), ptr(dsh), NREP,
+         npix, C, groups, act, int(accumulate_gx), dt, stream_ptr())
+    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    if dstats is None:
+        dstats = torch.empty((groups, 2, C), dtype=torch.float64, device=dev)
+    call("sdhip_bn_finalize_bwd", ptr(dsc), ptr(dsh), NREP, ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
+         ptr(dstats), dstats.stride(-2), int(accumulate_dstats), C, groups, float(count), int(train), stream_ptr())
+    return dgamma, dbeta, dstats
+
+
+def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_relu, groups, need_x, need_w, has_bias):
+    """dgrad (w.r.t. the post-prologue input) and wgrad of one conv; returns (g_post, gw, gb)."""
+    spec = ctx_spec
+    B, Cin, H, W = xv.shape
+    Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
+    dt = dtype_code(xv)
+    T = spec.kh * spec.kw
+    gpost = gw = gb = None
+    if need_x:
+        if spec.stride != 1:
+            raise _lib.SdhipError("data gradient of a strided convolution is not implemented (only image inputs feed one)")
+        wd = packed_weight(weight, spec.kind, 'dgrad', xv.dtype)
+        gpost = empty_nhwc(B, Cin, H, W, xv.dtype, xv.device)
+        pt = spec.dil * (spec.kh - 1) - spec.pad_t
+        pl = spec.dil * (spec.kw - 1) - spec.pad_l
+        _conv_launch(g, ldg, wd, gpost, Cin, None, None, None, None, B, spec.Ho, spec.Wo, Cout, H, W, Cin,
+                     spec.kh, spec.kw, 1, spec.dil, pt, pl, False, 1, 0, False)
+    if need_w:
+        acc = torch.empty(_lib.packed_elems(Cout, Cin, T, dt), dtype=torch.float32, device=xv.device)
+        gb = torch.empty(Cout, dtype=torch.float32, device=xv.device) if has_bias else None
+        call("sdhip_conv2d_wgrad", ptr(xv), ptr(g), ptr(acc), ptr(gb), ptr(in_scale), ptr(in_shift),
+             B, H, W, Cin, ldx, spec.Ho, spec.Wo, Cout, ldg, spec.kh, spec.kw, spec.stride, spec.dil,
+             spec.pad_t, spec.pad_l, int(in_relu), groups, dt, stream_ptr())
+        gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+        M, K, sm, sk, flip = _pack_params(spec.kind, 'fwd', Cout, Cin, T)
+        call("sdhip_conv_unpack_wgrad", ptr(acc), ptr(gw), M, K, T, sm, sk, flip, 0, dt, stream_ptr())
+    return gpost, gw, gb
+
+
 class _ConvFn(torch.autograd.Function):
-    """y (, stats) = conv(pro(x)); see sdhip_conv2d_fwd in include/sdhip.h."""
+    """y = act(conv(x) + bias)   (conv2dSame / ConvTranspose2dSame / nn.Conv2d without a BatchNorm behind it)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, in_scale, in_shift, spec, in_relu, groups, act, want_stats):
+    def forward(ctx, x, weight, bias, spec, act):
         _require_gpu(x, weight)
         B, Cin, H, W = x.shape
         xv, ldx = nhwc_view(x)
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
         wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
         y = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
-        stats = torch.zeros((groups, 2, Cout), dtype=torch.float64, device=x.device) if want_stats else None
-        b32 = bias.detach().float() if bias is not None else None
-        _conv_launch(xv, ldx, wp, y, Cout, b32, in_scale, in_shift, stats, B, H, W, Cin, spec.Ho, spec.Wo, Cout,
-                     spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, in_relu, groups, act, False)
-        ctx.spec, ctx.in_relu, ctx.groups, ctx.act, ctx.ldx = spec, in_relu, groups, act, ldx
-        ctx.has_bias = bias is not None
-        ctx.save_for_backward(xv, weight, in_scale, in_shift, y if (want_stats or act) else None)
-        if want_stats:
-            return y, stats
+        _conv_launch(xv, ldx, wp, y, Cout, bias.detach() if bias is not None else None, None, None, None, B, H, W, Cin,
+                     spec.Ho, spec.Wo, Cout, spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, 1, act, False)
+        ctx.spec, ctx.act, ctx.ldx, ctx.has_bias = spec, act, ldx, bias is not None
+        ctx.save_for_backward(xv, weight, y if act else None)
         return y
 
     @staticmethod
-    def backward(ctx, gy, gstats=None):
-        xv, weight, in_scale, in_shift, ysaved = ctx.saved_tensors
-        spec, groups, act, ldx = ctx.spec, ctx.groups, ctx.act, ctx.ldx
-        B, Cin, H, W = xv.shape
+    def backward(ctx, gy):
+        xv, weight, ysaved = ctx.saved_tensors
+        spec, act = ctx.spec, ctx.act
+        B = xv.shape[0]
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
-        dt = dtype_code(xv)
-        npix_o = B * spec.Ho * spec.Wo
         g, ldg = nhwc_view(gy)
-        if gstats is not None:      # gradient through the batch statistics of the BatchNorm that follows
+        if act:   # activation fused in the epilogue: derivative from the stored output
             g2 = empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
-            call("sdhip_stats_fix", ptr(g), ldg, ptr(ysaved), Cout, ptr(g2), Cout, ptr(gstats), gstats.stride(1),
-                 npix_o, Cout, groups, dt, stream_ptr())
+            call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(ysaved), Cout, ptr(g2), Cout, None, None, None, None, 1,
+                 B * spec.Ho * spec.Wo, Cout, 1, 1 if act == 1 else 4, 0, dtype_code(xv), stream_ptr())
             g, ldg = g2, Cout
-        if act:                     # activation fused in the epilogue: derivative from the stored output
-            g2 = empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
-            call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(ysaved), Cout, ptr(g2), Cout, None, None, None, None,
-                 npix_o, Cout, 1, 1 if act == 1 else 4, 0, dt, stream_ptr())
-            g, ldg = g2, Cout
-        gx = gscale = gshift = gw = gb = None
-        T = spec.kh * spec.kw
-        if ctx.needs_input_grad[0]:
-            if spec.stride != 1:
-                raise _lib.SdhipError("data gradient of a strided convolution is not implemented (only image inputs feed one)")
-            wd = packed_weight(weight, spec.kind, 'dgrad', xv.dtype)
-            gpost = empty_nhwc(B, Cin, H, W, xv.dtype, xv.device)
-            pt = spec.dil * (spec.kh - 1) - spec.pad_t
-            pl = spec.dil * (spec.kw - 1) - spec.pad_l
-            _conv_launch(g, ldg, wd, gpost, Cin, None, None, None, None, B, spec.Ho, spec.Wo, Cout, H, W, Cin,
-                         spec.kh, spec.kw, 1, spec.dil, pt, pl, False, 1, 0, False)
-            if in_scale is not None:
-                gx = empty_nhwc(B, Cin, H, W, xv.dtype, xv.device)
-                gscale = torch.empty_like(in_scale)
-                gshift = torch.empty_like(in_shift)
-                call("sdhip_affine_act_bwd", ptr(gpost), Cin, ptr(xv), ldx, ptr(gx), Cin, ptr(in_scale), ptr(in_shift),
-                     ptr(gscale), ptr(gshift), B * H * W, Cin, groups, 1 if ctx.in_relu else 0, 0, dt, stream_ptr())
-            else:
-                gx = gpost
-        elif in_scale is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
-            raise _lib.SdhipError("prologue gradients need the input gradient path")
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            acc = torch.empty(_lib.packed_elems(Cout, Cin, T, dt), dtype=torch.float32, device=xv.device)
-            gb = torch.empty(Cout, dtype=torch.float32, device=xv.device) if ctx.has_bias else None
-            call("sdhip_conv2d_wgrad", ptr(xv), ptr(g), ptr(acc), ptr(gb), ptr(in_scale), ptr(in_shift),
-                 B, H, W, Cin, ldx, spec.Ho, spec.Wo, Cout, ldg, spec.kh, spec.kw, spec.stride, spec.dil,
-                 spec.pad_t, spec.pad_l, int(ctx.in_relu), groups, dt, stream_ptr())
-            gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-            M, K, sm, sk, flip = _pack_params(spec.kind, 'fwd', Cout, Cin, T)
-            call("sdhip_conv_unpack_wgrad", ptr(acc), ptr(gw), M, K, T, sm, sk, flip, 0, dt, stream_ptr())
-        return gx, gw, gb, gscale, gshift, None, None, None, None, None
+        gx, gw, gb = _conv_backward(spec, xv, ctx.ldx, weight, g, ldg, None, None, False, 1, ctx.needs_input_grad[0],
+                                    ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]), ctx.has_bias)
+        return gx, gw, gb, None, None
+
+
+class _ConvBNActFn(torch.autograd.Function):
+    """y = act(BatchNorm(conv(x))) (+ residual) as ONE autograd node: the conv epilogue sums the batch statistics,
+    a per-channel kernel turns them into scale/shift (and updates the running statistics), one elementwise pass
+    normalises, activates and adds the skip.  convbn / deconvbn (+ReLU, + skip add) of models/dsnet_t2.py:16-117."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, spec, bn, act, groups):
+        _require_gpu(x, weight)
+        B, Cin, H, W = x.shape
+        xv, ldx = nhwc_view(x)
+        Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
+        wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
+        yraw = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
+        train = bn.training
+        ws = torch.zeros((NREP, groups, 2, Cout), dtype=torch.float64, device=x.device) if train else None
+        _conv_launch(xv, ldx, wp, yraw, Cout, None, None, None, ws, B, H, W, Cin, spec.Ho, spec.Wo, Cout,
+                     spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, groups, 0, False, NREP)
+        count = (B // groups) * spec.Ho * spec.Wo
+        scale, shift, mean, invstd = _bn_finalize(ws, NREP, bn, count, groups)
+        rv, ldr = nhwc_view(residual) if residual is not None else (None, 0)
+        y = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
+        call("sdhip_affine_act", ptr(yraw), Cout, ptr(y), Cout, ptr(rv), ldr, ptr(scale), ptr(shift), B * spec.Ho * spec.Wo,
+             Cout, groups, act, dtype_code(x), stream_ptr())
+        ctx.spec, ctx.act, ctx.groups, ctx.ldx, ctx.count, ctx.train = spec, act, groups, ldx, count, train
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(xv, weight, gamma, yraw, scale, shift, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xv, weight, gamma, yraw, scale, shift, mean, invstd = ctx.saved_tensors
+        spec, groups = ctx.spec, ctx.groups
+        B = xv.shape[0]
+        Cout = yraw.shape[1]
+        npix = B * spec.Ho * spec.Wo
+        dt = dtype_code(xv)
+        g, ldg = nhwc_view(gy)
+        graw = empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
+        dgamma, dbeta, dS = _bn_backward(g, ldg, yraw, Cout, graw, Cout, scale, shift, mean, invstd, gamma, npix, Cout,
+                                         groups, ctx.act, ctx.count, ctx.train, dt)
+        if ctx.train:
+            call("sdhip_stats_fix", ptr(graw), Cout, ptr(yraw), Cout, ptr(graw), Cout, ptr(dS), Cout, npix, Cout, groups,
+                 dt, stream_ptr())
+        gx, gw, _ = _conv_backward(spec, xv, ctx.ldx, weight, graw, Cout, None, None, False, 1, ctx.needs_input_grad[0],
+                                   ctx.needs_input_grad[1], False)
+        return gx, gw, dgamma, dbeta, (gy if ctx.has_res else None), None, None, None, None
+
+
+class _BNConvFn(torch.autograd.Function):
+    """y = conv(relu(BatchNorm(x))) with the statistics of x given (DenseNet transition, models/densenet.py:119-128):
+    norm + relu are the conv's fused input prologue.  Returns gradients for x and for its statistics."""
+
+    @staticmethod
+    def forward(ctx, x, stats, weight, gamma, beta, spec, bn, groups):
+        _require_gpu(x, weight)
+        B, Cin, H, W = x.shape
+        xv, ldx = nhwc_view(x)
+        Cout = weight.shape[0]
+        train = bn.training
+        count = (B // groups) * H * W
+        scale, shift, mean, invstd = _bn_finalize(stats if train else None, 1, bn, count, groups)
+        wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
+        y = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
+        _conv_launch(xv, ldx, wp, y, Cout, None, scale, shift, None, B, H, W, Cin, spec.Ho, spec.Wo, Cout,
+                     spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, True, groups, 0, False)
+        ctx.spec, ctx.groups, ctx.ldx, ctx.count, ctx.train = spec, groups, ldx, count, train
+        ctx.save_for_backward(xv, weight, gamma, scale, shift, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xv, weight, gamma, scale, shift, mean, invstd = ctx.saved_tensors
+        spec, groups = ctx.spec, ctx.groups
+        B, Cin, H, W = xv.shape
+        dt = dtype_code(xv)
+        g, ldg = nhwc_view(gy)
+        gpost, gw, _ = _conv_backward(spec, xv, ctx.ldx, weight, g, ldg, scale, shift, True, groups, True, True, False)
+        gx = empty_nhwc(B, Cin, H, W, xv.dtype, xv.device)
+        dgamma, dbeta, dS = _bn_backward(gpost, Cin, xv, ctx.ldx, gx, Cin, scale, shift, mean, invstd, gamma, B * H * W, Cin,
+                                         groups, 1, ctx.count, ctx.train, dt)
+        return gx, (dS if ctx.train else None), gw, dgamma, dbeta, None, None, None
+
+
+class _BNActFn(torch.autograd.Function):
+    """y = act(BatchNorm(x)) with the statistics of x given (norm5 of the DenseNet, models/densenet.py:239-241)."""
+
+    @staticmethod
+    def forward(ctx, x, stats, gamma, beta, bn, act, groups):
+        _require_gpu(x)
+        B, C, H, W = x.shape
+        xv, ldx = nhwc_view(x)
+        train = bn.training
+        count = (B // groups) * H * W
+        scale, shift, mean, invstd = _bn_finalize(stats if train else None, 1, bn, count, groups)
+        y = empty_nhwc(B, C, H, W, x.dtype, x.device)
+        call("sdhip_affine_act", ptr(xv), ldx, ptr(y), C, None, 0, ptr(scale), ptr(shift), B * H * W, C, groups, act,
+             dtype_code(x), stream_ptr())
+        ctx.cfg = (ldx, act, groups, count, train)
+        ctx.save_for_backward(xv, gamma, scale, shift, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xv, gamma, scale, shift, mean, invstd = ctx.saved_tensors
+        ldx, act, groups, count, train = ctx.cfg
+        B, C, H, W = xv.shape
+        g, ldg = nhwc_view(gy)
+        gx = empty_nhwc(B, C, H, W, xv.dtype, xv.device)
+        dgamma, dbeta, dS = _bn_backward(g, ldg, xv, ldx, gx, C, scale, shift, mean, invstd, gamma, B * H * W, C, groups, act,
+                                         count, train, dtype_code(xv))
+        return gx, (dS if train else None), dgamma, dbeta, None, None, None
 
 
 def conv_same_geometry(H, W, k, stride, dil):
@@ -242,8 +386,7 @@ def deconv_same_geometry(H, W, k, dil):
     return one(H), one(W)
 
 
-def conv2d(x, weight, bias=None, *, kind='conv', stride=1, dilation=1, padding=0, in_scale=None, in_shift=None,
-           in_relu=False, groups=1, act=0, want_stats=False):
+def conv_spec(x, weight, kind='conv', stride=1, dilation=1, padding=0):
     """padding: int (symmetric, nn.Conv2d), 'same' (conv2dSame) or 'ctsame' (stride-1 ConvTranspose2dSame)."""
     B, C, H, W = x.shape
     kh, kw = weight.shape[2], weight.shape[3]
@@ -260,117 +403,57 @@ def conv2d(x, weight, bias=None, *, kind='conv', stride=1, dilation=1, padding=0
         pt = pl = int(padding)
         Ho = (H + 2 * pt - dilation * (kh - 1) - 1) // stride + 1
         Wo = (W + 2 * pl - dilation * (kw - 1) - 1) // stride + 1
-    spec = ConvSpec(kind, kh, kw, stride, dilation, pt, pl, Ho, Wo)
-    return _ConvFn.apply(x, weight, bias, in_scale, in_shift, spec, in_relu, groups, act, want_stats)
+    return ConvSpec(kind, kh, kw, stride, dilation, pt, pl, Ho, Wo)
 
 
-# ============================================================================ batch norm pieces
-class _BNFinalizeFn(torch.autograd.Function):
-    """(stats, gamma, beta) -> (scale, shift); running statistics are updated in place in training mode."""
-
-    @staticmethod
-    def forward(ctx, stats, gamma, beta, running_mean, running_var, count, eps, momentum, groups):
-        C = gamma.numel()
-        dev = gamma.device
-        scale = torch.empty((groups, C), dtype=torch.float32, device=dev)
-        shift = torch.empty((groups, C), dtype=torch.float32, device=dev)
-        mean = torch.empty((groups, C), dtype=torch.float32, device=dev)
-        invstd = torch.empty((groups, C), dtype=torch.float32, device=dev)
-        call("sdhip_bn_finalize", ptr(stats), stats.stride(1) if stats is not None else 0, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-             ptr(scale), ptr(shift), ptr(mean), ptr(invstd), C, groups, float(count), float(eps),
-             float(momentum), stream_ptr())
-        ctx.save_for_backward(gamma, mean, invstd)
-        ctx.cfg = (C, groups, float(count), stats is not None)
-        return scale, shift
-
-    @staticmethod
-    def backward(ctx, gscale, gshift):
-        gamma, mean, invstd = ctx.saved_tensors
-        C, groups, count, train = ctx.cfg
-        dev = gamma.device
-        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-        dstats = torch.empty((groups, 2, C), dtype=torch.float64, device=dev) if train else None
-        call("sdhip_bn_finalize_bwd", ptr(gscale.contiguous()), ptr(gshift.contiguous()), ptr(gamma), ptr(mean), ptr(invstd),
-             ptr(dgamma), ptr(dbeta), ptr(dstats), C, 0, C, groups, count, int(train), stream_ptr())
-        return dstats, dgamma, dbeta, None, None, None, None, None, None
+def conv2d(x, weight, bias=None, *, kind='conv', stride=1, dilation=1, padding=0, act=0):
+    return _ConvFn.apply(x, weight, bias, conv_spec(x, weight, kind, stride, dilation, padding), act)
 
 
-def bn_scale_shift(bn, stats, count, groups=1):
-    """scale/shift of an nn.BatchNorm2d: from batch statistics (training; running stats updated like the
-    reference's sequential calls) or from the running statistics (eval)."""
-    if bn.training:
-        if stats is None:
-            raise _lib.SdhipError("training-mode BatchNorm needs batch statistics")
-        mom = 0.1 if bn.momentum is None else bn.momentum
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += groups
-        return _BNFinalizeFn.apply(stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, bn.eps, mom, groups)
-    return _BNFinalizeFn.apply(None, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, bn.eps, 0.0, groups)
+def conv_bn_act(x, weight, bn, *, kind='conv', stride=1, dilation=1, padding=0, act=0, residual=None, groups=1):
+    return _ConvBNActFn.apply(x, weight, bn.weight, bn.bias, residual, conv_spec(x, weight, kind, stride, dilation, padding),
+                              bn, act, groups)
+
+
+def bn_conv(x, stats, bn, weight, *, padding=0, groups=1):
+    """conv(relu(bn(x))) with x's batch statistics `stats` ([groups][2][C] f64) supplied by the producer of x."""
+    return _BNConvFn.apply(x, stats, weight, bn.weight, bn.bias, conv_spec(x, weight, 'conv', 1, 1, padding), bn, groups)
+
+
+def bn_act(x, stats, bn, act=1, groups=1):
+    return _BNActFn.apply(x, stats, bn.weight, bn.bias, bn, act, groups)
 
 
 class _AffineActFn(torch.autograd.Function):
-    """y = act(x*scale + shift) (+ residual)."""
+    """y = act(x*scale + shift) (+ residual) with CONSTANT scale/shift (no gradient to them)."""
 
     @staticmethod
-    def forward(ctx, x, scale, shift, residual, act, groups):
+    def forward(ctx, x, scale, shift, residual, act):
         _require_gpu(x)
         B, C, H, W = x.shape
         xv, ldx = nhwc_view(x)
         rv, ldr = nhwc_view(residual) if residual is not None else (None, 0)
         y = empty_nhwc(B, C, H, W, x.dtype, x.device)
-        call("sdhip_affine_act", ptr(xv), ldx, ptr(y), C, ptr(rv), ldr, ptr(scale), ptr(shift), B * H * W, C, groups, act,
+        call("sdhip_affine_act", ptr(xv), ldx, ptr(y), C, ptr(rv), ldr, ptr(scale), ptr(shift), B * H * W, C, 1, act,
              dtype_code(x), stream_ptr())
         ctx.save_for_backward(xv, scale, shift)
-        ctx.cfg = (ldx, act, groups, residual is not None)
+        ctx.cfg = (ldx, act, residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         xv, scale, shift = ctx.saved_tensors
-        ldx, act, groups, has_res = ctx.cfg
+        ldx, act, has_res = ctx.cfg
         B, C, H, W = xv.shape
         g, ldg = nhwc_view(gy)
         gx = empty_nhwc(B, C, H, W, xv.dtype, xv.device)
-        need = scale is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        gscale = torch.empty_like(scale) if need else None
-        gshift = torch.empty_like(shift) if need else None
-        call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(xv), ldx, ptr(gx), C, ptr(scale), ptr(shift), ptr(gscale), ptr(gshift),
-             B * H * W, C, groups, act, 0, dtype_code(xv), stream_ptr())
-        return gx, gscale, gshift, (gy if has_res else None), None, None
+        call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(xv), ldx, ptr(gx), C, ptr(scale), ptr(shift), None, None, 1,
+             B * H * W, C, 1, act, 0, dtype_code(xv), stream_ptr())
+        return gx, None, None, (gy if has_res else None), None
 
 
-def affine_act(x, scale=None, shift=None, residual=None, act=0, groups=1):
-    return _AffineActFn.apply(x, scale, shift, residual, act, groups)
-
-
-def channel_stats(x, groups=1):
-    """Batch statistics (f64 sum, sum of squares) of a tensor no conv epilogue produced them for."""
-    return _ChannelStatsFn.apply(x, groups)
-
-
-class _ChannelStatsFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, groups):
-        _require_gpu(x)
-        B, C, H, W = x.shape
-        xv, ldx = nhwc_view(x)
-        stats = torch.empty((groups, 2, C), dtype=torch.float64, device=x.device)
-        call("sdhip_channel_stats", ptr(xv), ldx, ptr(stats), C, B * H * W, C, groups, 1, dtype_code(x), stream_ptr())
-        ctx.save_for_backward(xv)
-        ctx.cfg = (ldx, groups)
-        return stats
-
-    @staticmethod
-    def backward(ctx, gstats):
-        (xv,) = ctx.saved_tensors
-        ldx, groups = ctx.cfg
-        B, C, H, W = xv.shape
-        zero = torch.zeros((B, H, W, C), dtype=xv.dtype, device=xv.device).permute(0, 3, 1, 2)
-        gx = empty_nhwc(B, C, H, W, xv.dtype, xv.device)
-        call("sdhip_stats_fix", ptr(zero), C, ptr(xv), ldx, ptr(gx), C, ptr(gstats), gstats.stride(1), B * H * W, C, groups,
-             dtype_code(xv), stream_ptr())
-        return gx, None
+def affine_act(x, scale=None, shift=None, residual=None, act=0):
+    return _AffineActFn.apply(x, scale, shift, residual, act)
 
 
 # ============================================================================ pooling / resize / concat / broadcast product

@@ -1,0 +1,23 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import ref_models as R
+from oracle.detweights import fill_state_dict, rand_input
+from pmt_learning_for_semantic_segmentation_and_disparity_amd.densenet import densenet121
+ref = fill_state_dict(R.densenet121(), 21).train()
+mine = densenet121(); mine.load_state_dict(ref.state_dict()); mine = mine.cuda().train()
+x = rand_input(21, "img", (2, 3, 256, 256))
+wts = [rand_input(22, "g%d" % i, (1,)).item() + 0.5 for i in range(5)]
+sum(w * (t * t).mean() for w, t in zip(wts, ref(x))).backward()
+sum(w * (t.float() * t.float()).mean() for w, t in zip(wts, mine(x.cuda()))).backward()
+rp = dict(ref.named_parameters())
+rows = []
+for k, p in mine.named_parameters():
+    if rp[k].grad is None: continue
+    want = rp[k].grad
+    rows.append((float((p.grad.cpu() - want).abs().max()) / max(1e-12, float(want.abs().max())),
+                 float(torch.linalg.norm(p.grad.cpu() - want) / torch.linalg.norm(want)), k, float(want.abs().max())))
+rows.sort(reverse=True)
+for r in rows[:12]: print("max-rel %.2e  l2-rel %.2e  %-50s |g|max %.2e" % r)
+import statistics
+print("median max-rel", statistics.median(r[0] for r in rows), "median l2-rel", statistics.median(r[1] for r in rows))

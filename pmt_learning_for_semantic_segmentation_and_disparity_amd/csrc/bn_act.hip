@@ -213,6 +213,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ S, int ldc, int nr
   float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
   for (int g = 0; g < G; ++g) {
     double s1 = 0., s2 = 0.;
+#pragma unroll 8
     for (int r = 0; r < nrep; ++r) {
       const double* Sr = S + (long)r * G * 2 * ldc;
       s1 += Sr[((long)g * 2 + 0) * ldc + c];
@@ -245,6 +246,7 @@ __global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const f
   float dg = 0.f, db = 0.f;
   for (int g = 0; g < G; ++g) {
     float ds = 0.f, dh = 0.f;
+#pragma unroll 8
     for (int r = 0; r < nrep; ++r) { ds += dscale[((long)r * G + g) * C + c]; dh += dshift[((long)r * G + g) * C + c]; }
     const float mu = mean[g * C + c], inv = invstd[g * C + c];
     const float t = ds - mu * dh;       // d/d(gamma*invstd) collected
@@ -306,6 +308,7 @@ __global__ void replica_sum_kernel(const double* __restrict__ ws, double* __rest
   if (i >= rows * C) return;
   const int row = i / C, c = i - row * C;
   double s = 0.;
+#pragma unroll 8
   for (int r = 0; r < nrep; ++r) s += ws[(long)r * rep_stride + (long)row * ldw + c];
   out[(long)row * ldo + c] += s;
 }

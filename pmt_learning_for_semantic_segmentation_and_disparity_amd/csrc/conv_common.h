@@ -56,19 +56,19 @@ struct StageSrc {
   int relu, vec;
 };
 
-template <typename T, int NB>
+template <typename T, int NB, int NT = 256>
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const StageSrc& s, int q, int sh, int tid) {
   constexpr int V = Chunk<T>::N;
   constexpr int CK = 8 * V;
   const int total = (s.IH * s.IW) << sh;
   const T* xb = (const T*)s.base;
-  for (int i0 = tid; i0 < total; i0 += 256 * NB) {
+  for (int i0 = tid; i0 < total; i0 += NT * NB) {
     u32x4 raw[NB];
     int ch[NB], off[NB];
     bool in[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int i = i0 + j * 256;
+      const int i = i0 + j * NT;
       const int pix = i >> sh, c = i & ((1 << sh) - 1);
       const int ih = pix / s.IW, iw = pix - ih * s.IW;
       const int gh = s.h0 + ih, gw = s.w0 + iw;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const StageSrc& s
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      if (i0 + j * 256 < total) {
+      if (i0 + j * NT < total) {
         if (s.scale && in[j]) {
           float f[V];
           Chunk<T>::unpack(raw[j], f);

@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int kMaxTaps = 9;  // taps per workgroup (accumulators stay in registers)
+constexpr int kThreads = 512;  // 8 waves: 2 per SIMD, up to 256 VGPRs each
 
 struct WgArgs {
   const void* x; const void* dy; float* dwp; float* dbias;
@@ -33,9 +33,9 @@ struct WgArgs {
 
 typedef __attribute__((address_space(3))) bf16x4_t* lds_bf4_ptr;
 
-// 16x16x32 bf16 operand fragment, pixel-major, from a [pixel][channel] LDS image.
-// `rows[h]` is the LDS row (pixel) this lane addresses in half h, i.e. pixel 8g + 4h + ((l&15)>>2);
-// `ch` the first channel of the 16-channel tile.
+// 16x16x32 bf16 operand fragment, pixel-major, from a [pixel][channel] LDS image (ds_read_b64_tr_b16 x2).
+// row0/row1: the LDS rows (pixels) this lane addresses, i.e. pixels 8g + ((l&15)>>2) and +4; `ch` the first
+// channel of the 16-channel tile.  EXEC must be full (the read crosses lanes).
 __device__ __forceinline__ u32x4 tr_frag(unsigned char* base, int row0, int row1, int ch, int lane) {
   const int p = lane & 3;                      // 4-channel sub-block this lane addresses
   const int c = (ch >> 3) + (p >> 1);          // 16-byte chunk
@@ -46,13 +46,23 @@ __device__ __forceinline__ u32x4 tr_frag(unsigned char* base, int row0, int row1
   return u32x4{l2[0], l2[1], h2[0], h2[1]};
 }
 
-template <typename T, int TH, int TW>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
+// One workgroup = (output-channel block of CK, input-channel chunk of CK, a group of <= MAXT taps).  Its 8 waves
+// split the CK x CK x taps accumulator: wave -> (16 input channels, half of the output channels[, tap parity]),
+// so that ALL taps of a 5x5 kernel (25 x 64 x 64 f32 partial sums = 400 KB) stay in registers while the workgroup
+// sweeps its share of the pixel tiles: X and dY are staged once per tile, not once per tap group.
+template <typename T, int TH, int TW, int MAXT, int MB>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgArgs p) {
   constexpr int V = Chunk<T>::N;
-  constexpr int CK = 8 * V;                 // channels per LDS row = output-channel block = input-channel chunk
-  constexpr int NTILE = CK / 16;            // 16-channel MFMA tiles per chunk: 4 (bf16) / 2 (f32)
-  constexpr int NCO = NTILE * NTILE / 4;    // output-channel tiles per wave: 4 (bf16) / 1 (f32)
+  constexpr int CK = 8 * V;                 // channels per LDS row = input-channel chunk
   constexpr bool BF = sizeof(T) == 2;
+  constexpr int NTILE = CK / 16;            // 16-channel MFMA tiles per input chunk: 4 (bf16) / 2 (f32)
+  constexpr int NW = kThreads / 64;
+  constexpr int NREST = NW / NTILE;         // waves per input-channel tile: 2 (bf16) / 4 (f32)
+  constexpr int NCO = BF ? 2 : 1;           // output-channel tiles per wave
+  constexpr int COG = (MB / 16) / NCO;      // output-channel groups across waves
+  constexpr int TAPL = NREST / COG;         // waves sharing a (ci, co) block, interleaved over the taps
+  constexpr int MAXTW = (MAXT + TAPL - 1) / TAPL;
+  static_assert(COG >= 1 && TAPL >= 1 && COG * TAPL == NREST && MB <= CK, "wave decomposition");
   constexpr int KSTEP = BF ? 32 : 4;        // pixels per MFMA k-step
   static_assert((TH * TW) % 32 == 0, "tile must be whole k-steps");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -63,59 +73,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
   const int s = g.stride, d = g.dil;
   const int IH = (TH - 1) * s + (g.kh - 1) * d + 1, IW = (TW - 1) * s + (g.kw - 1) * d + 1;
   const int T_ = g.kh * g.kw;
-  // blockIdx.y -> (output-channel block, channel chunk, tap group)
-  int by = blockIdx.y;
+  int by = blockIdx.y;                       // -> (output-channel block, channel chunk, tap group)
   const int tgi = by % p.ntg; by /= p.ntg;
   const int q = by % p.nq;
   const int mb = by / p.nq;
   const int t0 = tgi * p.tpb, nt = min(p.tpb, T_ - t0);
-  const int m0 = mb * CK;
-  const int ci_tile = wave % NTILE;          // this wave's 16 input channels of the chunk
-  const int co_tile0 = (wave / NTILE) * NCO;  // first output-channel tile of this wave
+  const int m0 = mb * MB;
+  const int ci_tile = wave % NTILE;
+  const int rest = wave / NTILE;
+  const int co_tile0 = (rest % COG) * NCO;
+  const int tap_lane = rest / COG;
   const int cin_q = min(CK, p.Cin - q * CK);
-  const int cout_m = min(CK, p.Cout - m0);
+  const int cout_m = min(MB, p.Cout - m0);
   const int shx = (cin_q + CK / 2 - 1) / (CK / 2) == 2 ? 3 : 2;   // data chunks per X row: 8 or 4
   const int shy = (cout_m + CK / 2 - 1) / (CK / 2) == 2 ? 3 : 2;
 
   unsigned char* halo = smem;
   unsigned char* ytile = smem + ((IH * IW * 128 + 15) & ~15);
 
-  f32x4 acc[kMaxTaps][NCO];
+  f32x4 acc[MAXTW][NCO];
 #pragma unroll
-  for (int t = 0; t < kMaxTaps; ++t)
+  for (int t = 0; t < MAXTW; ++t)
 #pragma unroll
     for (int mi = 0; mi < NCO; ++mi) acc[t][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;  // bias gradient partial of channel (tid % CK), pixel stripe (tid / CK)
 
   const int tiles_w = (g.Wo + TW - 1) / TW, tiles_h = (g.Ho + TH - 1) / TH;
   const int ntiles = g.B * tiles_h * tiles_w;
-  const bool wave_active = ci_tile * 16 < cin_q;  // wave-uniform
+  const bool wave_active = ci_tile * 16 < cin_q && co_tile0 * 16 < cout_m;  // wave-uniform
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / (tiles_h * tiles_w);
     const int tr = tile - b * tiles_h * tiles_w;
     const int oh0 = (tr / tiles_w) * TH, ow0 = (tr % tiles_w) * TW;
-    const int ih0 = oh0 * s - g.pad_t, iw0 = ow0 * s - g.pad_l;
     const int grp = p.groups > 1 ? b / (g.B / p.groups) : 0;
     const T* xb = (const T*)p.x + (long)b * g.H * g.W * p.ldx;
     const T* yb = (const T*)p.dy + (long)b * g.Ho * g.Wo * p.lddy;
     __syncthreads();  // previous tile's fragments are consumed
-    // ---- stage the X halo tile of channel chunk q (same image as the forward kernel) ----
-    {
+    {   // X halo tile of channel chunk q (same LDS image as the forward kernel, fused prologue)
       StageSrc ss;
-      ss.base = xb; ss.H = g.H; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin; ss.h0 = ih0; ss.w0 = iw0; ss.IH = IH; ss.IW = IW;
+      ss.base = xb; ss.H = g.H; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin;
+      ss.h0 = oh0 * s - g.pad_t; ss.w0 = ow0 * s - g.pad_l; ss.IH = IH; ss.IW = IW;
       ss.scale = p.in_scale ? p.in_scale + grp * p.Cin : nullptr;
       ss.shift = p.in_scale ? p.in_shift + grp * p.Cin : nullptr;
       ss.relu = p.in_relu; ss.vec = p.vec_x;
-      stage_tile<T, 4>(halo, ss, q, shx, tid);
+      stage_tile<T, 4, kThreads>(halo, ss, q, shx, tid);
     }
-    // ---- stage the dY tile of output-channel block mb (a TH x TW tile with no halo; channels offset by m0) ----
-    {
+    {   // dY tile of output-channel block mb (TH x TW, no halo; channels offset by m0)
       StageSrc ss;
-      ss.base = yb + m0; ss.H = g.Ho; ss.W = g.Wo; ss.ld = p.lddy; ss.C = p.Cout - m0; ss.h0 = oh0; ss.w0 = ow0; ss.IH = TH; ss.IW = TW;
+      ss.base = yb + m0; ss.H = g.Ho; ss.W = g.Wo; ss.ld = p.lddy; ss.C = p.Cout - m0;
+      ss.h0 = oh0; ss.w0 = ow0; ss.IH = TH; ss.IW = TW;
       ss.scale = nullptr; ss.shift = nullptr; ss.relu = 0;
-      ss.vec = p.vec_dy && ((m0 * (int)sizeof(T)) % 16 == 0);
-      stage_tile<T, 4>(ytile, ss, 0, shy, tid);
+      ss.vec = p.vec_dy;
+      stage_tile<T, 2, kThreads>(ytile, ss, 0, shy, tid);
     }
     __syncthreads();
 
@@ -123,16 +133,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
       const int ch = tid % CK, stripe = tid / CK;
       if (ch < cout_m) {
         const int c = ch / V, e = ch % V;
-        for (int pix = stripe; pix < TH * TW; pix += 256 / CK)
+        for (int pix = stripe; pix < TH * TW; pix += kThreads / CK)
           bsum += Elem<T>::ld(reinterpret_cast<const T*>(ytile + lds_off(pix, c)) + e);
       }
     }
 
-    // ---- MFMA over the tile's pixels ----
+    // ---- MFMA over the tile's pixels (the contraction index) ----
     for (int k0 = 0; k0 < TH * TW; k0 += KSTEP) {
       if constexpr (BF) {
-        // this lane addresses pixels k0 + 8*lg + 4*h + ((l15)>>2), h = 0,1
-        const int pa = k0 + 8 * lg + (l15 >> 2);
+        const int pa = k0 + 8 * lg + (l15 >> 2);   // this lane addresses pixels pa and pa + 4
         const int pb = pa + 4;
         u32x4 af[NCO];
 #pragma unroll
@@ -140,16 +149,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
         const int ha = ((pa / TW) * s) * IW + (pa % TW) * s;
         const int hb = ((pb / TW) * s) * IW + (pb % TW) * s;
 #pragma unroll
-        for (int tl = 0; tl < kMaxTaps; ++tl) {
-          if (tl < nt) {
-            const int t = t0 + tl;
+        for (int tl = 0; tl < MAXTW; ++tl) {
+          const int tt = tl * TAPL + tap_lane;
+          if (tt < nt) {   // wave-uniform
+            const int t = t0 + tt;
             const int khi = t / g.kw, kwi = t - khi * g.kw;
             const int toff = (khi * d) * IW + kwi * d;
             const u32x4 bf = tr_frag(halo, ha + toff, hb + toff, ci_tile * 16, lane);
-            if (wave_active) {
 #pragma unroll
-              for (int mi = 0; mi < NCO; ++mi) Mma<T>::run(acc[tl][mi], af[mi], bf);
-            }
+            for (int mi = 0; mi < NCO; ++mi) Mma<T>::run(acc[tl][mi], af[mi], bf);
           }
         }
       } else {
@@ -164,17 +172,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
         }
         const int chx = ci_tile * 16 + l15;
 #pragma unroll
-        for (int tl = 0; tl < kMaxTaps; ++tl) {
-          if (tl < nt) {
-            const int t = t0 + tl;
+        for (int tl = 0; tl < MAXTW; ++tl) {
+          const int tt = tl * TAPL + tap_lane;
+          if (tt < nt) {
+            const int t = t0 + tt;
             const int khi = t / g.kw, kwi = t - khi * g.kw;
             const int row = hk + (khi * d) * IW + kwi * d;
             const float bv = *reinterpret_cast<const float*>(halo + lds_off(row, chx >> 2) + ((chx & 3) << 2));
-            if (wave_active) {
 #pragma unroll
-              for (int mi = 0; mi < NCO; ++mi)
-                acc[tl][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bv, acc[tl][mi], 0, 0, 0);
-            }
+            for (int mi = 0; mi < NCO; ++mi)
+              acc[tl][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bv, acc[tl][mi], 0, 0, 0);
           }
         }
       }
@@ -184,9 +191,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
   // ---- flush: f32 atomics into the packed gradient buffer [nq][T][Mpad][CK] ----
   if (wave_active) {
 #pragma unroll
-    for (int tl = 0; tl < kMaxTaps; ++tl) {
-      if (tl < nt) {
-        float* dst = p.dwp + ((long)(q * T_ + t0 + tl) * p.Mpad) * CK;
+    for (int tl = 0; tl < MAXTW; ++tl) {
+      const int tt = tl * TAPL + tap_lane;
+      if (tt < nt) {
+        float* dst = p.dwp + ((long)(q * T_ + t0 + tt) * p.Mpad) * CK;
 #pragma unroll
         for (int mi = 0; mi < NCO; ++mi) {
 #pragma unroll
@@ -204,29 +212,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs p) {
   }
 }
 
-template <typename T, int TH, int TW>
+template <typename T, int TH, int TW, int MAXT, int MB>
 int launch(const WgArgs& a, hipStream_t s) {
-  auto kern = conv_wgrad_kernel<T, TH, TW>;
+  auto kern = conv_wgrad_kernel<T, TH, TW, MAXT, MB>;
   const ConvGeom& g = a.g;
   const int IH = (TH - 1) * g.stride + (g.kh - 1) * g.dil + 1, IW = (TW - 1) * g.stride + (g.kw - 1) * g.dil + 1;
   const size_t lds = (((size_t)IH * IW * 128 + 15) & ~(size_t)15) + (size_t)TH * TW * 128;
-  if (lds > 160 * 1024) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_wgrad: halo tile does not fit LDS (k=%dx%d dil=%d)", g.kh, g.kw, g.dil);
+  if (lds > 160 * 1024) return 1;  // caller falls back to a smaller tile
   static size_t attr_set = 0;
   if (lds > 64 * 1024 && attr_set == 0) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: cannot raise dynamic LDS limit");
     attr_set = 1;
   }
-  const int CK = 8 * Chunk<T>::N;
-  const int nmb = sdhip_cdiv(a.Cout, CK);
+  const int nmb = sdhip_cdiv(a.Cout, MB);
   const int gy = nmb * a.nq * a.ntg;
   const int ntiles = g.B * sdhip_cdiv(g.Ho, TH) * sdhip_cdiv(g.Wo, TW);
-  int gx = sdhip_cdiv(1024, gy);
+  const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+  int gx = sdhip_cdiv(256 * per_cu, gy);
   if (gx > ntiles) gx = ntiles;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(kThreads), lds, s, a);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
+}
+
+template <typename T, int MAXT, int MB>
+int launch_tile(const WgArgs& a, bool wide, hipStream_t s) {
+  if (wide) {
+    const int rc = launch<T, 8, 32, MAXT, MB>(a, s);
+    if (rc != 1) return rc;
+    const int rc2 = launch<T, 4, 32, MAXT, MB>(a, s);
+    if (rc2 != 1) return rc2;
+  }
+  const int rc = launch<T, 4, 16, MAXT, MB>(a, s);
+  if (rc == 1) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_wgrad: halo tile does not fit LDS (k=%dx%d dil=%d)", a.g.kh, a.g.kw, a.g.dil);
+  return rc;
 }
 
 // ---- weight (un)packing -------------------------------------------------------
@@ -317,8 +338,9 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
   a.Cin = Cin; a.ldx = ldx; a.Cout = Cout; a.Mpad = (Cout + 15) & ~15; a.lddy = lddy;
   a.in_relu = in_relu; a.groups = groups;
   a.nq = sdhip_cdiv(Cin, CK);
-  a.ntg = sdhip_cdiv(T, kMaxTaps);
-  a.tpb = sdhip_cdiv(T, a.ntg);  // balanced tap groups (25 -> 9,8,8)
+  const int maxt = T <= 9 ? 9 : 25;          // taps a workgroup keeps in registers
+  a.ntg = sdhip_cdiv(T, maxt);
+  a.tpb = sdhip_cdiv(T, a.ntg);              // balanced tap groups (49 -> 25, 24)
   a.ntg = sdhip_cdiv(T, a.tpb);
   a.vec_x = (Cin % V == 0) && (ldx % V == 0) && (((uintptr_t)x & 15) == 0);
   a.vec_dy = (Cout % V == 0) && (lddy % V == 0) && (((uintptr_t)dy & 15) == 0);
@@ -327,6 +349,7 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
   if (hipMemsetAsync(dw_packed, 0, n * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
   if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
   const bool wide = Wo >= 24;
-  if (dtype == SDHIP_BF16) return wide ? launch<bf16_t, 4, 32>(a, s) : launch<bf16_t, 4, 16>(a, s);
-  return wide ? launch<float, 4, 32>(a, s) : launch<float, 4, 16>(a, s);
+  // bf16, 25 taps: 25 x (64 x 64) partial sums do not fit 8 waves' registers -> 32 output channels per workgroup
+  if (dtype == SDHIP_BF16) return maxt == 9 ? launch_tile<bf16_t, 9, 64>(a, wide, s) : launch_tile<bf16_t, 25, 32>(a, wide, s);
+  return maxt == 9 ? launch_tile<float, 9, 32>(a, wide, s) : launch_tile<float, 25, 32>(a, wide, s);
 }

@@ -113,13 +113,17 @@ int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                      int kh, int kw, int stride, int dil, int pad_t, int pad_l,
                      int in_relu, int groups, int act, int accumulate,
                      int dtype, void* stream);
-/* dW (packed f32, zeroed here) = sum over pixels of dy (x) pro(x); dbias[m] = sum dy (optional). */
+/* prezeroed != 0: the caller already zeroed dw_packed / dbias (one arena memset per step instead of one per call).
+ * dW (packed f32, zeroed here) = sum over pixels of dy (x) pro(x); dbias[m] = sum dy (optional). */
 int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* dbias,
                        const float* in_scale, const float* in_shift,
                        int B, int H, int W, int Cin, int ldx,
                        int Ho, int Wo, int Cout, int lddy,
                        int kh, int kw, int stride, int dil, int pad_t, int pad_l,
-                       int in_relu, int groups, int dtype, void* stream);
+                       int in_relu, int groups, int prezeroed, int dtype, void* stream);
+/* Pack many weights in one launch: desc = ndesc rows of 8 int64 {src ptr, dst ptr, M, K, T, stride_m, stride_k, flip}
+ * in device memory (same layout rules as sdhip_conv_pack_weights). */
+int sdhip_conv_pack_batch(const long* desc, int ndesc, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * BatchNorm2d in training mode (+ ReLU / sigmoid / skip add), decomposed so the
@@ -143,7 +147,7 @@ int sdhip_bn_finalize(const double* stats, int stats_ld, int stats_nrep, const f
 /* (dscale,dshift)[g][c] -> dgamma[c], dbeta[c] and dstats[g][2][c] (gradient w.r.t. S1, S2; zero in eval). */
 int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, int nrep, const float* gamma,
                           const float* mean, const float* invstd,
-                          float* dgamma, float* dbeta, double* dstats, int stats_ld, int accumulate_dstats,
+                          float* dgamma, float* dbeta, double* dstats, int stats_ld, int accumulate_flags /* bit0: dstats +=, bit1: dgamma/dbeta += */,
                           int C, int groups, double count, int train, void* stream);
 /* y = act(x*scale[g][c] + shift[g][c]) (+ res). scale/shift may be NULL (identity). */
 int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const void* res, int ldr,
@@ -154,7 +158,7 @@ int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const void* res, 
  * gx (+)= gy*act'*scale (if gx != NULL; += when accumulate != 0); dscale = sum gy*act'*x, dshift = sum gy*act' (if non-NULL; zeroed here). */
 int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
                          const float* scale, const float* shift, float* dscale, float* dshift, int nrep,
-                         long npix, int C, int groups, int act, int accumulate, int dtype, void* stream);
+                         long npix, int C, int groups, int act, int accumulate, int prezeroed, int dtype, void* stream);
 /* out[row][c] += sum_r ws[r][row][c] over the 2*groups statistics rows (folds conv-epilogue replicas into a slab). */
 int sdhip_stats_replica_sum(const double* ws, double* out, int nrep, int groups, int C, int ldw, int ldo, void* stream);
 /* gout = gin + dstats[g][0][c] + 2*x*dstats[g][1][c]: the gradient that flows through the batch statistics. */

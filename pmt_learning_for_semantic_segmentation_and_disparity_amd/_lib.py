@@ -40,13 +40,14 @@ SIGNATURES = {
     "sdhip_conv_pack_weights": [_p, _p, _i, _i, _i, _l, _l, _i, _i, _p],
     "sdhip_conv_unpack_wgrad": [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p],
     "sdhip_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 22 + [_p],
-    "sdhip_conv2d_wgrad": [_p, _p, _p, _p, _p, _p] + [_i] * 18 + [_p],
+    "sdhip_conv2d_wgrad": [_p, _p, _p, _p, _p, _p] + [_i] * 19 + [_p],
+    "sdhip_conv_pack_batch": [_p, _i, _i, _p],
     "sdhip_channel_stats": [_p, _i, _p, _i, _i, _l, _i, _i, _i, _i, _p],
     "sdhip_stats_replica_sum": [_p, _p, _i, _i, _i, _i, _i, _p],
     "sdhip_bn_finalize": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _d, _f, _f, _p],
     "sdhip_bn_finalize_bwd": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _i, _p],
     "sdhip_affine_act": [_p, _i, _p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _i, _p],
-    "sdhip_affine_act_bwd": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _l, _i, _i, _i, _i, _i, _p],
+    "sdhip_affine_act_bwd": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _l, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_maxpool3s2_fwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     "sdhip_maxpool3s2_bwd": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_avgpool_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -238,11 +238,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ S, int ldc, int nr
 // (dscale, dshift)[G][C] -> dgamma[C], dbeta[C] (summed over groups), dS[G][2][C]
 __global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift, int nrep,
                                        const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, double* __restrict__ dS, int ldc, int acc_ds,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, double* __restrict__ dS, int ldc, int acc_flags,
                                        int C, int G, double count, int train) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float gm = gamma ? gamma[c] : 1.f;
+  const int acc_ds = acc_flags & 1, acc_par = acc_flags & 2;   // bit 0: dstats += ; bit 1: dgamma/dbeta +=
   float dg = 0.f, db = 0.f;
   for (int g = 0; g < G; ++g) {
     float ds = 0.f, dh = 0.f;
@@ -267,8 +268,8 @@ __global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const f
       }
     }
   }
-  if (dgamma) dgamma[c] = dg;
-  if (dbeta) dbeta[c] = db;
+  if (dgamma) dgamma[c] = acc_par ? dgamma[c] + dg : dg;
+  if (dbeta) dbeta[c] = acc_par ? dbeta[c] + db : db;
 }
 
 template <typename T>
@@ -348,14 +349,14 @@ extern "C" int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const 
 
 extern "C" int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
                                     const float* scale, const float* shift, float* dscale, float* dshift, int nrep,
-                                    long npix, int C, int groups, int act, int accumulate, int dtype, void* stream) {
+                                    long npix, int C, int groups, int act, int accumulate, int prezeroed, int dtype, void* stream) {
   if (nrep < 1) nrep = 1;
   const int G = groups;
   if (int rc = check_rows("affine_act_bwd", npix, C, G, dtype)) return rc;
   SDHIP_CHECK_ARG(gy && x && ldg >= C && ldx >= C && (!gx || ldgx >= C), "affine_act_bwd: bad pointers/strides");
   SDHIP_CHECK_ARG((dscale == nullptr) == (dshift == nullptr), "affine_act_bwd: dscale/dshift must come together");
   hipStream_t s = (hipStream_t)stream;
-  if (dscale) {
+  if (dscale && !prezeroed) {
     if (hipMemsetAsync(dscale, 0, sizeof(float) * (size_t)nrep * G * C, s) != hipSuccess ||
         hipMemsetAsync(dshift, 0, sizeof(float) * (size_t)nrep * G * C, s) != hipSuccess)
       SDHIP_FAIL(SDHIP_ERR_LAUNCH, "affine_act_bwd: memset failed");

@@ -287,11 +287,18 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   a.rep_stride = (long)groups * 2 * a.stats_ld;
   a.vec_in = (Cin % V == 0) && (ldx % V == 0) && (((uintptr_t)x & 15) == 0);
   a.vec_out = (ldy % 4 == 0) && (((uintptr_t)y % (4 * es)) == 0);
-  const int bn = a.Mpad > 64 ? 128 : (a.Mpad > 32 ? 64 : (a.Mpad > 16 ? 32 : 16));
-  const int rows = a.Mpad < bn ? a.Mpad : bn;
+  int bn = a.Mpad > 64 ? 128 : (a.Mpad > 32 ? 64 : (a.Mpad > 16 ? 32 : 16));
   const int T = kh * kw;
   const long blocks_big = (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) * B * sdhip_cdiv(a.Mpad, bn);
   bool big = blocks_big >= 512 && Wo >= 24;
+  if (!big) {
+    // small feature maps (DenseNet blocks 2-4, pooled pyramids): the launch cannot fill 256 CUs with pixel tiles alone,
+    // so split the output channels over more workgroups (the input tile is re-read from L2, the serial
+    // chunk-by-chunk latency chain per workgroup gets shorter and more of them overlap per CU).
+    const long px_blocks = (long)sdhip_cdiv(Ho, 4) * sdhip_cdiv(Wo, 16) * B;
+    while (bn > 32 && px_blocks * sdhip_cdiv(a.Mpad, bn) < 1024) bn >>= 1;
+  }
+  const int rows = a.Mpad < bn ? a.Mpad : bn;
   const size_t kMax = 160 * 1024, kSoft = 64 * 1024;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int th = big ? 8 : 4, tw = big ? 32 : 16;

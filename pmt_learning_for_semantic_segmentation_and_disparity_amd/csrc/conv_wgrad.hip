@@ -308,6 +308,38 @@ extern "C" int sdhip_conv_pack_weights(const float* src, void* dst, int M, int K
   return SDHIP_OK;
 }
 
+// One launch packs every weight of the network: desc[i] = {src ptr, dst ptr, M, K, T, stride_m, stride_k, flip}.
+template <typename T>
+__global__ void pack_batch_kernel(const long* __restrict__ desc) {
+  constexpr int CK = 8 * Chunk<T>::N;
+  const long* d = desc + (long)blockIdx.y * 8;
+  const float* src = reinterpret_cast<const float*>(d[0]);
+  T* dst = reinterpret_cast<T*>(d[1]);
+  const int M = (int)d[2], K = (int)d[3], Tn = (int)d[4], flip = (int)d[7];
+  const long sm = d[5], sk = d[6];
+  const int Mpad = (M + 15) & ~15;
+  const long total = (long)((K + CK - 1) / CK) * Tn * Mpad * CK;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CK);
+    long r = i / CK;
+    const int m = (int)(r % Mpad); r /= Mpad;
+    const int t = (int)(r % Tn);
+    const int k = (int)(r / Tn) * CK + c;
+    float v = 0.f;
+    if (m < M && k < K) v = src[m * sm + k * sk + (flip ? Tn - 1 - t : t)];
+    Elem<T>::st(dst + i, v);
+  }
+}
+
+extern "C" int sdhip_conv_pack_batch(const long* desc, int ndesc, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(desc && ndesc > 0, "conv_pack_batch: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv_pack_batch: unknown dtype %d", dtype);
+  if (dtype == SDHIP_BF16) hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, dim3(16, ndesc), dim3(256), 0, (hipStream_t)stream, desc);
+  else hipLaunchKernelGGL(pack_batch_kernel<float>, dim3(16, ndesc), dim3(256), 0, (hipStream_t)stream, desc);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
 extern "C" int sdhip_conv_unpack_wgrad(const float* acc, float* grad, int M, int K, int T,
                                        long stride_m, long stride_k, int flip, int accumulate, int dtype, void* stream) {
   SDHIP_CHECK_ARG(acc && grad && M > 0 && K > 0 && T > 0, "conv_unpack_wgrad: bad arguments");
@@ -324,7 +356,7 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
                                   int B, int H, int W, int Cin, int ldx,
                                   int Ho, int Wo, int Cout, int lddy,
                                   int kh, int kw, int stride, int dil, int pad_t, int pad_l,
-                                  int in_relu, int groups, int dtype, void* stream) {
+                                  int in_relu, int groups, int prezeroed, int dtype, void* stream) {
   SDHIP_CHECK_ARG(x && dy && dw_packed, "conv2d_wgrad: null pointer");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv2d_wgrad: unknown dtype %d", dtype);
   SDHIP_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_wgrad: empty tensor");
@@ -346,8 +378,10 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
   a.vec_dy = (Cout % V == 0) && (lddy % V == 0) && (((uintptr_t)dy & 15) == 0);
   hipStream_t s = (hipStream_t)stream;
   const long n = sdhip_conv_packed_elems(Cout, Cin, T, dtype);
-  if (hipMemsetAsync(dw_packed, 0, n * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
-  if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
+  if (!prezeroed) {
+    if (hipMemsetAsync(dw_packed, 0, n * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
+    if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
+  }
   const bool wide = Wo >= 24;
   // bf16, 25 taps: 25 x (64 x 64) partial sums do not fit 8 waves' registers -> 32 output channels per workgroup
   if (dtype == SDHIP_BF16) return maxt == 9 ? launch_tile<bf16_t, 9, 64>(a, wide, s) : launch_tile<bf16_t, 25, 32>(a, wide, s);

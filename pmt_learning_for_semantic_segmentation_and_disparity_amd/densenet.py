@@ -29,18 +29,20 @@ from ._lib import call, dtype_code, ptr, stream_ptr
 NREP = ops.NREP
 
 
-def _finalize(stats, nrep, bn, count, groups, training):
-    return ops._bn_finalize(stats if training else None, nrep, bn, count, groups)
+def _finalize(stats, nrep, bn, count, groups, training, synced=False):
+    return ops._bn_finalize(stats if training else None, nrep, bn, count, groups, synced=synced)
+
+
+def _fold(ws, S_slice, groups, C, Ct):
+    """Fold conv-epilogue replicas (summed over ranks when data parallel) into a channel slice of the slab statistics."""
+    ws, nrep = ops._sync_stats(ws, NREP)
+    call("sdhip_stats_replica_sum", ptr(ws), ptr(S_slice), nrep, groups, C, C, Ct, stream_ptr())
 
 
 def _wgrad(x, ldx, dy, lddy, weight, B, H, W, Cin, Cout, k, pad, in_scale, in_shift, groups, dt):
-    """dW of a stride-1 nn.Conv2d (weight (Cout,Cin,k,k)) whose input is prologue(x)."""
-    T = k * k
-    acc = torch.empty(ops._lib.packed_elems(Cout, Cin, T, dt), dtype=torch.float32, device=weight.device)
-    call("sdhip_conv2d_wgrad", ptr(x), ptr(dy), ptr(acc), None, ptr(in_scale), ptr(in_shift), B, H, W, Cin, ldx,
-         H, W, Cout, lddy, k, k, 1, 1, pad, pad, 1, groups, dt, stream_ptr())
-    gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-    call("sdhip_conv_unpack_wgrad", ptr(acc), ptr(gw), Cout, Cin, T, Cin * T, T, 0, 0, dt, stream_ptr())
+    """dW of a stride-1 nn.Conv2d (weight (Cout,Cin,k,k)) whose input is relu(prologue(x)); x is a (B,Cin,H,W) view."""
+    spec = ops.ConvSpec('conv', k, k, 1, 1, pad, pad, H, W)
+    gw, _ = ops.wgrad(x[:, :Cin], ldx, dy, lddy, weight, None, spec, in_scale, in_shift, True, groups)
     return gw
 
 
@@ -67,24 +69,23 @@ class _DenseBlockFn(torch.autograd.Function):
         if training:   # statistics of the incoming features (the producer was a pool, not a conv epilogue)
             ws0 = torch.empty((NREP, groups, 2, C0), dtype=torch.float64, device=dev)
             call("sdhip_channel_stats", ptr(slab), Ct, ptr(ws0), C0, NREP, npix, C0, groups, 1, dt, stream_ptr())
-            call("sdhip_stats_replica_sum", ptr(ws0), ptr(S), NREP, groups, C0, C0, Ct, stream_ptr())
+            _fold(ws0, S[:, :, :C0], groups, C0, Ct)
         saved = []
         for li, layer in enumerate(layers):
             Cin = C0 + li * growth
-            sc1, sh1, mu1, iv1 = _finalize(S[:, :, :Cin], 1, layer.norm1, count, groups, training)
+            sc1, sh1, mu1, iv1 = _finalize(S[:, :, :Cin], 1, layer.norm1, count, groups, training, synced=True)
             w1 = ops.packed_weight(layer.conv1.weight, 'conv', 'fwd', dtype)
             y1 = ops.empty_nhwc(B, mid, H, W, dtype, dev)
-            S2 = torch.zeros((NREP, groups, 2, mid), dtype=torch.float64, device=dev) if training else None
+            S2 = ops._zeros((NREP, groups, 2, mid), torch.float64, dev)[0] if training else None
             ops._conv_launch(slab, Ct, w1, y1, mid, None, sc1, sh1, S2, B, H, W, Cin, H, W, mid, 1, 1, 1, 1, 0, 0,
                              True, groups, 0, False, NREP)
             sc2, sh2, mu2, iv2 = _finalize(S2, NREP, layer.norm2, count, groups, training)
             w2 = ops.packed_weight(layer.conv2.weight, 'conv', 'fwd', dtype)
-            S3 = torch.zeros((NREP, groups, 2, growth), dtype=torch.float64, device=dev) if training else None
+            S3 = ops._zeros((NREP, groups, 2, growth), torch.float64, dev)[0] if training else None
             ops._conv_launch(y1, mid, w2, slab[:, Cin:Cin + growth], Ct, None, sc2, sh2, S3, B, H, W, mid, H, W, growth,
                              3, 3, 1, 1, 1, 1, True, groups, 0, False, NREP)
             if training:   # fold the replicas into this layer's slice of the slab statistics
-                call("sdhip_stats_replica_sum", ptr(S3), ptr(S[:, :, Cin:Cin + growth]), NREP, groups, growth, growth, Ct,
-                     stream_ptr())
+                _fold(S3, S[:, :, Cin:Cin + growth], groups, growth, Ct)
             saved.append((y1, sc1, sh1, mu1, iv1, sc2, sh2, mu2, iv2))
         ctx.block, ctx.groups, ctx.saved, ctx.slab = block, groups, saved, slab
         ctx.geom = (B, C0, H, W, growth, mid, Ct, training, count)
@@ -123,7 +124,7 @@ class _DenseBlockFn(torch.autograd.Function):
             gw2 = _wgrad(y1, mid, dy2, growth, layer.conv2.weight, B, H, W, mid, growth, 3, 1, sc2, sh2, groups, dt)
             # (3) through relu + norm2's affine, (4) norm2's statistics, (5) into y1
             dg2, db2, dS2 = ops._bn_backward(gp2, mid, y1, mid, gp2, mid, sc2, sh2, mu2, iv2, layer.norm2.weight, npix, mid,
-                                             groups, 1, count, training, dt)
+                                             groups, 1, count, training, dt, beta=layer.norm2.bias)
             if training:
                 call("sdhip_stats_fix", ptr(gp2), mid, ptr(y1), mid, ptr(gp2), mid, ptr(dS2), mid, npix, mid, groups, dt, st)
             # (6) conv1 (1x1): data gradient w.r.t. relu(norm1(slab[:Cin])), weight gradient
@@ -135,7 +136,7 @@ class _DenseBlockFn(torch.autograd.Function):
             # (7) through relu + norm1's affine, accumulated into the slab gradient; (8) norm1's statistics -> dS
             dg1, db1, _ = ops._bn_backward(gp1, Cin, slab, Ct, g_slab, Ct, sc1, sh1, mu1, iv1, layer.norm1.weight, npix, Cin,
                                            groups, 1, count, training, dt, accumulate_gx=True, dstats=dS[:, :, :Cin],
-                                           accumulate_dstats=True)
+                                           accumulate_dstats=True, beta=layer.norm1.bias)
             grads.append((dg1, db1, gw1, dg2, db2, gw2))
         gx0 = ops.empty_nhwc(B, C0, H, W, dtype, dev)
         call("sdhip_stats_fix", ptr(g_slab), Ct, ptr(slab), Ct, ptr(gx0), C0, ptr(dS), Ct, npix, C0, groups, dt, st)
@@ -157,7 +158,7 @@ class _Stem(torch.autograd.Function):
         wp = ops.packed_weight(weight, 'conv', 'fwd', x.dtype)
         c0 = ops.empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
         train = bn.training
-        ws = torch.zeros((NREP, groups, 2, Cout), dtype=torch.float64, device=x.device) if train else None
+        ws = ops._zeros((NREP, groups, 2, Cout), torch.float64, x.device)[0] if train else None
         ops._conv_launch(xv, ldx, wp, c0, Cout, None, None, None, ws, B, H, W, Cin, spec.Ho, spec.Wo, Cout, 7, 7, 2, 1, 3, 3,
                          False, groups, 0, False, NREP)
         count = (B // groups) * spec.Ho * spec.Wo
@@ -166,12 +167,12 @@ class _Stem(torch.autograd.Function):
         call("sdhip_affine_act", ptr(c0), Cout, ptr(f), Cout, None, 0, ptr(scale), ptr(shift), B * spec.Ho * spec.Wo, Cout,
              groups, 1, dtype_code(x), stream_ptr())
         ctx.cfg = (spec, groups, ldx, count, train)
-        ctx.save_for_backward(xv, weight, gamma, c0, scale, shift, mean, invstd)
+        ctx.save_for_backward(xv, weight, gamma, beta, c0, scale, shift, mean, invstd)
         return c0, f
 
     @staticmethod
     def backward(ctx, g0, gf):
-        xv, weight, gamma, c0, scale, shift, mean, invstd = ctx.saved_tensors
+        xv, weight, gamma, beta, c0, scale, shift, mean, invstd = ctx.saved_tensors
         spec, groups, ldx, count, train = ctx.cfg
         B, Cout = c0.shape[0], c0.shape[1]
         npix = B * spec.Ho * spec.Wo
@@ -182,11 +183,11 @@ class _Stem(torch.autograd.Function):
         call("sdhip_affine_act", ptr(gv), ldg, ptr(graw), Cout, None, 0, None, None, npix, Cout, 1, 0, dt, stream_ptr())
         fv, ldf = ops.nhwc_view(gf)
         dgamma, dbeta, dS = ops._bn_backward(fv, ldf, c0, Cout, graw, Cout, scale, shift, mean, invstd, gamma, npix, Cout,
-                                             groups, 1, count, train, dt, accumulate_gx=True)
+                                             groups, 1, count, train, dt, accumulate_gx=True, beta=beta)
         if train:
             call("sdhip_stats_fix", ptr(graw), Cout, ptr(c0), Cout, ptr(graw), Cout, ptr(dS), Cout, npix, Cout, groups, dt,
                  stream_ptr())
-        _, gw, _ = ops._conv_backward(spec, xv, ldx, weight, graw, Cout, None, None, False, 1, False, True, False)
+        _, gw, _ = ops._conv_backward(spec, xv, ldx, weight, graw, Cout, None, None, False, 1, False, True)
         return None, gw, dgamma, dbeta, None, None
 
 

@@ -293,15 +293,21 @@ class minidsnetExt(nn.Module):
 
     def forward(self, input_a, input_b, pos=None, disp_gt=None, seg_gt=None):
         _no_dropout(self.conv1d_at_d[2].p, self.training)
-        B = input_a.shape[0]
-        both = torch.cat([input_a, input_b], 0)
+        B, _, H, W = input_a.shape
+        # both images in one NHWC buffer, channels zero-padded 3 -> 8: one pixel = one 16-byte chunk, so the image convs
+        # (conv0 7x7/2, conv2d_ba* 5x5 dil 2) stage their input with vector loads; the padded weight columns are zero.
+        both8 = torch.zeros((2 * B, H, W, 8), dtype=input_a.dtype, device=input_a.device)
+        both8[:B, :, :, :3] = input_a.permute(0, 2, 3, 1)
+        both8[B:, :, :, :3] = input_b.permute(0, 2, 3, 1)
+        both = both8.permute(0, 3, 1, 2)
+        img_a = both[:B]
         t = self.resnet_features(both, groups=2)          # taps of both towers, batch = [left | right]
         a = [u[:B] for u in t]
         b = [u[B:] for u in t]
-        xl3 = self.conv2d_ba3[0].fused(input_a, act=1)    # computed (and unused) exactly as in the reference
-        xl2 = self.conv2d_ba1[0].fused(input_a, act=1)
-        xl1 = self.conv2d_ba2[0].fused(input_a, act=1)
-        xl0 = self.conv2d_ba0[0].fused(input_a, act=1)
+        xl3 = self.conv2d_ba3[0].fused(img_a, act=1)      # computed (and unused) exactly as in the reference
+        xl2 = self.conv2d_ba1[0].fused(img_a, act=1)
+        xl1 = self.conv2d_ba2[0].fused(img_a, act=1)
+        xl0 = self.conv2d_ba0[0].fused(img_a, act=1)
         del xl3
         x, x1, seg1 = self.segNet(ops.concat([a[4], b[4]]), input_a, input_b, xl0)
 

@@ -83,6 +83,70 @@ def correlation(in1, in2, patch_h, patch_w, dilation_patch=1):
 # ============================================================================ convolution
 import weakref
 
+class StepContext:
+    """Per-training-step services installed by train.TrainStep (all optional; ops work without one):
+      * zero arena: every small zero-initialised workspace of the step (statistics replicas, packed f32 weight-gradient
+        accumulators, dscale/dshift replicas) is bump-allocated from ONE buffer that a single memset clears per step;
+      * frozen weight packs: all weights are packed by one batched launch at step start;
+      * direct gradients: parameter gradients are written (accumulated) straight into the flat gradient buffer;
+      * deferred num_batches_tracked increments (one multi-tensor add per step).
+    """
+
+    def __init__(self, device):
+        self.device = device
+        self.arena = None
+        self.offset = 0
+        self.measured = 0
+        self.frozen_pack = False
+        self.direct_grads = False
+        self.nbt = None          # list of (tensor, increment) recorded while measuring
+
+    def begin_step(self):
+        if self.arena is not None:
+            self.offset = 0
+            self.arena.zero_()
+
+    def zeros(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = ((n * torch.empty((), dtype=dtype).element_size() + 255) // 256) * 256
+        if self.arena is None:
+            self.measured += nbytes
+            return torch.zeros(shape, dtype=dtype, device=self.device), False
+        if self.offset + nbytes > self.arena.numel():
+            raise _lib.SdhipError("zero arena exhausted (%d + %d > %d)" % (self.offset, nbytes, self.arena.numel()))
+        t = self.arena[self.offset:self.offset + n * torch.empty((), dtype=dtype).element_size()].view(dtype).view(shape)
+        self.offset += nbytes
+        return t, True
+
+    def allocate_arena(self):
+        self.arena = torch.zeros(int(self.measured * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+
+
+_ctx = [None]
+
+
+def set_step_context(ctx):
+    _ctx[0] = ctx
+
+
+def _zeros(shape, dtype, device):
+    """(tensor of zeros, prezeroed flag for the C ABI)."""
+    c = _ctx[0]
+    if c is not None:
+        return c.zeros(shape, dtype)
+    return torch.zeros(shape, dtype=dtype, device=device), False
+
+
+def _grad_target(param):
+    """The flat-gradient slice to accumulate a parameter gradient into, or None (then the Function returns the gradient)."""
+    c = _ctx[0]
+    if c is not None and c.direct_grads and param is not None and param.grad is not None:
+        return param.grad
+    return None
+
+
 _pack_cache = {}   # id(weight parameter) -> (weakref, {(mode, dtype): (version, packed)})
 _pack_generation = [0]
 
@@ -115,8 +179,11 @@ def packed_weight(weight, kind, mode, dtype):
     Cout, Cin = (weight.shape[0], weight.shape[1]) if kind == 'conv' else (weight.shape[1], weight.shape[0])
     T = weight.shape[2] * weight.shape[3]
     ent = _cache_entry(weight)
-    key = (mode, dtype)
+    key = (kind, mode, dtype)
     hit = ent.get(key)
+    c = _ctx[0]
+    if hit is not None and c is not None and c.frozen_pack:
+        return hit[1]           # packed by the batched launch at step start (train.TrainStep.pack_all)
     ver = (weight._version, _pack_generation[0])
     if hit is not None and hit[0] == ver and not torch.cuda.is_current_stream_capturing():
         return hit[1]
@@ -129,6 +196,23 @@ def packed_weight(weight, kind, mode, dtype):
     call("sdhip_conv_pack_weights", ptr(w), ptr(buf), M, K, T, sm, sk, flip, dt, stream_ptr())
     ent[key] = (ver, buf)
     return buf
+
+
+def pack_descriptors(dtype):
+    """int64 [n][8] descriptor table {src, dst, M, K, T, stride_m, stride_k, flip} of every cached pack of `dtype`."""
+    rows = []
+    for ref, ent in _pack_cache.values():
+        w = ref()
+        if w is None:
+            continue
+        for (kind, mode, dt), (_, buf) in ent.items():
+            if dt != dtype:
+                continue
+            Cout, Cin = (w.shape[0], w.shape[1]) if kind == 'conv' else (w.shape[1], w.shape[0])
+            T = w.shape[2] * w.shape[3]
+            M, K, sm, sk, flip = _pack_params(kind, mode, Cout, Cin, T)
+            rows.append([w.data_ptr(), buf.data_ptr(), M, K, T, sm, sk, flip])
+    return rows
 
 
 class ConvSpec:
@@ -151,16 +235,39 @@ def _conv_launch(x, ldx, wp, y, ldy, bias, in_scale, in_shift, stats, B, H, W, C
 
 NREP = _lib.NREP
 
+from . import parallel  # noqa: E402
 
-def _bn_finalize(stats, nrep, bn, count, groups):
-    """(scale, shift, mean, invstd), each f32 [groups][C]; stats None => eval mode (running statistics)."""
+
+def _sync_stats(stats, nrep):
+    """Data parallel: fold the replicas, all-reduce the compact f64 (sum, sum of squares) over ranks (sync-BN)."""
+    if stats is None or parallel.world_size() == 1:
+        return stats, nrep
+    G, _, C = stats.shape[-3:]
+    compact = torch.zeros((G, 2, C), dtype=torch.float64, device=stats.device)
+    call("sdhip_stats_replica_sum", ptr(stats), ptr(compact), nrep, G, C, stats.stride(-2), C, stream_ptr())
+    parallel.all_reduce_sum_(compact)
+    return compact, 1
+
+
+def _bn_finalize(stats, nrep, bn, count, groups, synced=False):
+    """(scale, shift, mean, invstd), each f32 [groups][C]; stats None => eval mode (running statistics).
+    `count` is the LOCAL element count per group; under data parallelism statistics and count become global."""
     C = bn.num_features
     dev = bn.weight.device
+    if not synced:      # `synced`: the statistics were already summed over ranks (slab statistics of a dense block)
+        stats, nrep = _sync_stats(stats, nrep)
+    count = parallel.global_count(count)
     out = [torch.empty((groups, C), dtype=torch.float32, device=dev) for _ in range(4)]
     if stats is not None:
         mom = 0.1 if bn.momentum is None else bn.momentum
         if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += groups
+            c = _ctx[0]
+            if c is not None and c.nbt is not None and c.arena is not None:
+                pass                                                  # applied by one multi-tensor add per step (train.TrainStep)
+            else:
+                if c is not None and c.nbt is not None:
+                    c.nbt.append((bn.num_batches_tracked, groups))   # recorded during the measuring step
+                bn.num_batches_tracked += groups
         call("sdhip_bn_finalize", ptr(stats), stats.stride(-2), nrep, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
              ptr(bn.running_var), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, groups, float(count),
              float(bn.eps), float(mom), stream_ptr())
@@ -171,25 +278,39 @@ def _bn_finalize(stats, nrep, bn, count, groups):
 
 
 def _bn_backward(gy, ldg, x, ldx, gx, ldgx, scale, shift, mean, invstd, gamma, npix, C, groups, act, count, train,
-                 dt, accumulate_gx=False, dstats=None, accumulate_dstats=False):
+                 dt, accumulate_gx=False, dstats=None, accumulate_dstats=False, beta=None):
     """Backward of y = act(x*scale + shift) with scale/shift from batch statistics.
     Writes gx (+)= gy*act'*scale and returns (dgamma, dbeta, dstats[groups][2][C]); the caller still has to add the
     statistics path dstats[0] + 2*x*dstats[1] (sdhip_stats_fix) to the gradient of whatever produced x."""
     dev = scale.device
-    dsc = torch.empty((NREP, groups, C), dtype=torch.float32, device=dev)
-    dsh = torch.empty((NREP, groups, C), dtype=torch.float32, device=dev)
+    both, pz = _zeros((2, NREP, groups, C), torch.float32, dev)
+    dsc, dsh = both[0], both[1]
     call("sdhip_affine_act_bwd", ptr(gy), ldg, ptr(x), ldx, ptr(gx), ldgx, ptr(scale), ptr(shift), ptr(dsc), ptr(dsh), NREP,
-         npix, C, groups, act, int(accumulate_gx), dt, stream_ptr())
-    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+         npix, C, groups, act, int(accumulate_gx), int(pz), dt, stream_ptr())
+    tg, tb = _grad_target(gamma), _grad_target(beta)
+    direct = tg is not None and tb is not None
+    dgamma = tg if direct else torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = tb if direct else torch.empty(C, dtype=torch.float32, device=dev)
+    par_flag = 2 if direct else 0
     if dstats is None:
         dstats = torch.empty((groups, 2, C), dtype=torch.float64, device=dev)
+        accumulate_dstats = False
+    if parallel.world_size() > 1 and train:
+        # sync-BN backward: dgamma/dbeta from the LOCAL sums, the statistics gradient from the GLOBAL sums
+        call("sdhip_bn_finalize_bwd", ptr(dsc), ptr(dsh), NREP, ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
+             None, C, par_flag, C, groups, float(count), 1, stream_ptr())
+        glob = torch.stack((dsc.sum(0), dsh.sum(0)))          # [2][groups][C]
+        parallel.all_reduce_sum_(glob)
+        call("sdhip_bn_finalize_bwd", ptr(glob[0]), ptr(glob[1]), 1, ptr(gamma), ptr(mean), ptr(invstd), None, None,
+             ptr(dstats), dstats.stride(-2), int(accumulate_dstats), C, groups, float(parallel.global_count(count)), 1,
+             stream_ptr())
+        return (None, None, dstats) if direct else (dgamma, dbeta, dstats)
     call("sdhip_bn_finalize_bwd", ptr(dsc), ptr(dsh), NREP, ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
-         ptr(dstats), dstats.stride(-2), int(accumulate_dstats), C, groups, float(count), int(train), stream_ptr())
-    return dgamma, dbeta, dstats
+         ptr(dstats), dstats.stride(-2), int(accumulate_dstats) | par_flag, C, groups, float(count), int(train), stream_ptr())
+    return (None, None, dstats) if direct else (dgamma, dbeta, dstats)
 
 
-def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_relu, groups, need_x, need_w, has_bias):
+def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_relu, groups, need_x, need_w, bias=None):
     """dgrad (w.r.t. the post-prologue input) and wgrad of one conv; returns (g_post, gw, gb)."""
     spec = ctx_spec
     B, Cin, H, W = xv.shape
@@ -197,6 +318,7 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
     dt = dtype_code(xv)
     T = spec.kh * spec.kw
     gpost = gw = gb = None
+    has_bias = bias is not None
     if need_x:
         if spec.stride != 1:
             raise _lib.SdhipError("data gradient of a strided convolution is not implemented (only image inputs feed one)")
@@ -207,15 +329,45 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
         _conv_launch(g, ldg, wd, gpost, Cin, None, None, None, None, B, spec.Ho, spec.Wo, Cout, H, W, Cin,
                      spec.kh, spec.kw, 1, spec.dil, pt, pl, False, 1, 0, False)
     if need_w:
-        acc = torch.empty(_lib.packed_elems(Cout, Cin, T, dt), dtype=torch.float32, device=xv.device)
-        gb = torch.empty(Cout, dtype=torch.float32, device=xv.device) if has_bias else None
-        call("sdhip_conv2d_wgrad", ptr(xv), ptr(g), ptr(acc), ptr(gb), ptr(in_scale), ptr(in_shift),
-             B, H, W, Cin, ldx, spec.Ho, spec.Wo, Cout, ldg, spec.kh, spec.kw, spec.stride, spec.dil,
-             spec.pad_t, spec.pad_l, int(in_relu), groups, dt, stream_ptr())
-        gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-        M, K, sm, sk, flip = _pack_params(spec.kind, 'fwd', Cout, Cin, T)
-        call("sdhip_conv_unpack_wgrad", ptr(acc), ptr(gw), M, K, T, sm, sk, flip, 0, dt, stream_ptr())
+        gw, gb = wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu, groups)
     return gpost, gw, gb
+
+
+def wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale=None, in_shift=None, in_relu=False, groups=1):
+    """Weight (and bias) gradient of one conv.  Returns (gw, gb), each None when it was accumulated straight into the
+    flat gradient buffer (StepContext.direct_grads)."""
+    B, Cin, H, W = xv.shape
+    Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
+    dt = dtype_code(xv)
+    T = spec.kh * spec.kw
+    acc, pz = _zeros((_lib.packed_elems(Cout, Cin, T, dt),), torch.float32, xv.device)
+    tw = _grad_target(weight)
+    tb = _grad_target(bias) if bias is not None else None
+    gb = None
+    if bias is not None:
+        if tb is not None:
+            dbias, dbias_pz = tb, True       # the flat gradient buffer is zeroed once per step; the kernel adds
+        else:
+            dbias, dbias_pz = _zeros((Cout,), torch.float32, xv.device)
+            gb = dbias
+    else:
+        dbias, dbias_pz = None, True
+    if bias is not None and pz != dbias_pz:   # one flag covers both buffers: zero the not-yet-zeroed one here
+        if not pz:
+            acc.zero_()
+        elif tb is None:
+            dbias.zero_()
+        pz = True
+    call("sdhip_conv2d_wgrad", ptr(xv), ptr(g), ptr(acc), ptr(dbias), ptr(in_scale), ptr(in_shift),
+         B, H, W, Cin, ldx, spec.Ho, spec.Wo, Cout, ldg, spec.kh, spec.kw, spec.stride, spec.dil,
+         spec.pad_t, spec.pad_l, int(in_relu), groups, int(pz), dt, stream_ptr())
+    M, K, sm, sk, flip = _pack_params(spec.kind, 'fwd', Cout, Cin, T)
+    if tw is not None:
+        call("sdhip_conv_unpack_wgrad", ptr(acc), ptr(tw), M, K, T, sm, sk, flip, 1, dt, stream_ptr())
+        return None, gb
+    gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+    call("sdhip_conv_unpack_wgrad", ptr(acc), ptr(gw), M, K, T, sm, sk, flip, 0, dt, stream_ptr())
+    return gw, gb
 
 
 class _ConvFn(torch.autograd.Function):
@@ -231,13 +383,13 @@ class _ConvFn(torch.autograd.Function):
         y = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
         _conv_launch(xv, ldx, wp, y, Cout, bias.detach() if bias is not None else None, None, None, None, B, H, W, Cin,
                      spec.Ho, spec.Wo, Cout, spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, 1, act, False)
-        ctx.spec, ctx.act, ctx.ldx, ctx.has_bias = spec, act, ldx, bias is not None
-        ctx.save_for_backward(xv, weight, y if act else None)
+        ctx.spec, ctx.act, ctx.ldx = spec, act, ldx
+        ctx.save_for_backward(xv, weight, bias, y if act else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xv, weight, ysaved = ctx.saved_tensors
+        xv, weight, bias, ysaved = ctx.saved_tensors
         spec, act = ctx.spec, ctx.act
         B = xv.shape[0]
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
@@ -245,10 +397,10 @@ class _ConvFn(torch.autograd.Function):
         if act:   # activation fused in the epilogue: derivative from the stored output
             g2 = empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
             call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(ysaved), Cout, ptr(g2), Cout, None, None, None, None, 1,
-                 B * spec.Ho * spec.Wo, Cout, 1, 1 if act == 1 else 4, 0, dtype_code(xv), stream_ptr())
+                 B * spec.Ho * spec.Wo, Cout, 1, 1 if act == 1 else 4, 0, 0, dtype_code(xv), stream_ptr())
             g, ldg = g2, Cout
         gx, gw, gb = _conv_backward(spec, xv, ctx.ldx, weight, g, ldg, None, None, False, 1, ctx.needs_input_grad[0],
-                                    ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]), ctx.has_bias)
+                                    ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]), bias)
         return gx, gw, gb, None, None
 
 
@@ -266,7 +418,7 @@ class _ConvBNActFn(torch.autograd.Function):
         wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
         yraw = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
         train = bn.training
-        ws = torch.zeros((NREP, groups, 2, Cout), dtype=torch.float64, device=x.device) if train else None
+        ws = _zeros((NREP, groups, 2, Cout), torch.float64, x.device)[0] if train else None
         _conv_launch(xv, ldx, wp, yraw, Cout, None, None, None, ws, B, H, W, Cin, spec.Ho, spec.Wo, Cout,
                      spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, groups, 0, False, NREP)
         count = (B // groups) * spec.Ho * spec.Wo
@@ -277,12 +429,12 @@ class _ConvBNActFn(torch.autograd.Function):
              Cout, groups, act, dtype_code(x), stream_ptr())
         ctx.spec, ctx.act, ctx.groups, ctx.ldx, ctx.count, ctx.train = spec, act, groups, ldx, count, train
         ctx.has_res = residual is not None
-        ctx.save_for_backward(xv, weight, gamma, yraw, scale, shift, mean, invstd)
+        ctx.save_for_backward(xv, weight, gamma, beta, yraw, scale, shift, mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xv, weight, gamma, yraw, scale, shift, mean, invstd = ctx.saved_tensors
+        xv, weight, gamma, beta, yraw, scale, shift, mean, invstd = ctx.saved_tensors
         spec, groups = ctx.spec, ctx.groups
         B = xv.shape[0]
         Cout = yraw.shape[1]
@@ -291,12 +443,12 @@ class _ConvBNActFn(torch.autograd.Function):
         g, ldg = nhwc_view(gy)
         graw = empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
         dgamma, dbeta, dS = _bn_backward(g, ldg, yraw, Cout, graw, Cout, scale, shift, mean, invstd, gamma, npix, Cout,
-                                         groups, ctx.act, ctx.count, ctx.train, dt)
+                                         groups, ctx.act, ctx.count, ctx.train, dt, beta=beta)
         if ctx.train:
             call("sdhip_stats_fix", ptr(graw), Cout, ptr(yraw), Cout, ptr(graw), Cout, ptr(dS), Cout, npix, Cout, groups,
                  dt, stream_ptr())
         gx, gw, _ = _conv_backward(spec, xv, ctx.ldx, weight, graw, Cout, None, None, False, 1, ctx.needs_input_grad[0],
-                                   ctx.needs_input_grad[1], False)
+                                   ctx.needs_input_grad[1])
         return gx, gw, dgamma, dbeta, (gy if ctx.has_res else None), None, None, None, None
 
 
@@ -312,26 +464,26 @@ class _BNConvFn(torch.autograd.Function):
         Cout = weight.shape[0]
         train = bn.training
         count = (B // groups) * H * W
-        scale, shift, mean, invstd = _bn_finalize(stats if train else None, 1, bn, count, groups)
+        scale, shift, mean, invstd = _bn_finalize(stats if train else None, 1, bn, count, groups, synced=True)
         wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
         y = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
         _conv_launch(xv, ldx, wp, y, Cout, None, scale, shift, None, B, H, W, Cin, spec.Ho, spec.Wo, Cout,
                      spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, True, groups, 0, False)
         ctx.spec, ctx.groups, ctx.ldx, ctx.count, ctx.train = spec, groups, ldx, count, train
-        ctx.save_for_backward(xv, weight, gamma, scale, shift, mean, invstd)
+        ctx.save_for_backward(xv, weight, gamma, beta, scale, shift, mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xv, weight, gamma, scale, shift, mean, invstd = ctx.saved_tensors
+        xv, weight, gamma, beta, scale, shift, mean, invstd = ctx.saved_tensors
         spec, groups = ctx.spec, ctx.groups
         B, Cin, H, W = xv.shape
         dt = dtype_code(xv)
         g, ldg = nhwc_view(gy)
-        gpost, gw, _ = _conv_backward(spec, xv, ctx.ldx, weight, g, ldg, scale, shift, True, groups, True, True, False)
+        gpost, gw, _ = _conv_backward(spec, xv, ctx.ldx, weight, g, ldg, scale, shift, True, groups, True, True)
         gx = empty_nhwc(B, Cin, H, W, xv.dtype, xv.device)
         dgamma, dbeta, dS = _bn_backward(gpost, Cin, xv, ctx.ldx, gx, Cin, scale, shift, mean, invstd, gamma, B * H * W, Cin,
-                                         groups, 1, ctx.count, ctx.train, dt)
+                                         groups, 1, ctx.count, ctx.train, dt, beta=beta)
         return gx, (dS if ctx.train else None), gw, dgamma, dbeta, None, None, None
 
 
@@ -345,23 +497,23 @@ class _BNActFn(torch.autograd.Function):
         xv, ldx = nhwc_view(x)
         train = bn.training
         count = (B // groups) * H * W
-        scale, shift, mean, invstd = _bn_finalize(stats if train else None, 1, bn, count, groups)
+        scale, shift, mean, invstd = _bn_finalize(stats if train else None, 1, bn, count, groups, synced=True)
         y = empty_nhwc(B, C, H, W, x.dtype, x.device)
         call("sdhip_affine_act", ptr(xv), ldx, ptr(y), C, None, 0, ptr(scale), ptr(shift), B * H * W, C, groups, act,
              dtype_code(x), stream_ptr())
         ctx.cfg = (ldx, act, groups, count, train)
-        ctx.save_for_backward(xv, gamma, scale, shift, mean, invstd)
+        ctx.save_for_backward(xv, gamma, beta, scale, shift, mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xv, gamma, scale, shift, mean, invstd = ctx.saved_tensors
+        xv, gamma, beta, scale, shift, mean, invstd = ctx.saved_tensors
         ldx, act, groups, count, train = ctx.cfg
         B, C, H, W = xv.shape
         g, ldg = nhwc_view(gy)
         gx = empty_nhwc(B, C, H, W, xv.dtype, xv.device)
         dgamma, dbeta, dS = _bn_backward(g, ldg, xv, ldx, gx, C, scale, shift, mean, invstd, gamma, B * H * W, C, groups, act,
-                                         count, train, dtype_code(xv))
+                                         count, train, dtype_code(xv), beta=beta)
         return gx, (dS if train else None), dgamma, dbeta, None, None, None
 
 
@@ -448,7 +600,7 @@ class _AffineActFn(torch.autograd.Function):
         g, ldg = nhwc_view(gy)
         gx = empty_nhwc(B, C, H, W, xv.dtype, xv.device)
         call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(xv), ldx, ptr(gx), C, ptr(scale), ptr(shift), None, None, 1,
-             B * H * W, C, 1, act, 0, dtype_code(xv), stream_ptr())
+             B * H * W, C, 1, act, 0, 0, dtype_code(xv), stream_ptr())
         return gx, None, None, (gy if has_res else None), None
 
 

@@ -7,7 +7,7 @@ data-parallel); activations run in `dtype` (bf16 MFMA path or exact f32 path).
 """
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, parallel
 from ._lib import call, ptr, stream_ptr
 
 
@@ -35,6 +35,7 @@ class TrainStep:
         self.model, self.dtype, self.use_lovasz = model, dtype, use_lovasz
         self.lr, self.betas, self.eps = lr, betas, eps
         self.world_size, self.pg = world_size, process_group
+        parallel.configure(process_group, world_size)     # sync-BN statistics exchange + gradient all-reduce
         self.flat_p, self.flat_g = flatten_parameters(model)
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
@@ -43,18 +44,41 @@ class TrainStep:
         self.graph = None
         self.static = None
         self.loss = None
+        # per-step services (ops.StepContext): the first eager step measures / records, later steps use them
+        self.ctx = ops.StepContext(self.flat_p.device)
+        self.ctx.nbt = []
+        self.pack_desc = None
+        self.steps_done = 0
 
     # -- pieces ---------------------------------------------------------------------------------
+    def _arm(self):
+        """After the first (measuring) step: allocate the zero arena, freeze the weight packs into one batched
+        launch, switch parameter gradients to direct accumulation into the flat buffer."""
+        self.ctx.allocate_arena()
+        rows = ops.pack_descriptors(self.dtype)
+        self.pack_desc = torch.tensor(rows, dtype=torch.int64, device=self.flat_p.device) if rows else None
+        self.ctx.frozen_pack = self.pack_desc is not None
+        self.ctx.direct_grads = True
+        self.nbt_tensors = [t for t, _ in self.ctx.nbt]
+        self.nbt_incs = [int(i) for _, i in self.ctx.nbt]
+
+    def pack_all(self):
+        if self.ctx.frozen_pack:
+            call("sdhip_conv_pack_batch", ptr(self.pack_desc), self.pack_desc.shape[0],
+                 _lib.BF16 if self.dtype == torch.bfloat16 else _lib.F32, stream_ptr())
+
     def forward_backward(self, left, right, seg, disp):
+        ops.set_step_context(self.ctx)
+        self.ctx.begin_step()       # one memset clears every zero-initialised workspace of the step
         self.flat_g.zero_()
+        self.pack_all()             # one launch packs every weight (forward and data-grad orientation)
         outs = self.model(left.to(self.dtype), right.to(self.dtype))
         loss = ops.train_loss(outs[0], outs[1], outs[2], seg, disp, self.use_lovasz)
         loss.backward()
         return loss.detach()
 
     def all_reduce(self):
-        if self.world_size > 1:
-            torch.distributed.all_reduce(self.flat_g, group=self.pg)   # RCCL sum over xGMI; Adam divides by world_size
+        parallel.all_reduce_sum_(self.flat_g)   # one RCCL sum over xGMI per step; Adam divides by world_size
 
     def optimizer_step(self):
         call("sdhip_adam_step", ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.beta_pow),
@@ -65,6 +89,11 @@ class TrainStep:
         loss = self.forward_backward(left, right, seg, disp)
         self.all_reduce()
         self.optimizer_step()
+        if self.ctx.arena is None:
+            self._arm()
+        elif self.nbt_tensors:
+            torch._foreach_add_(self.nbt_tensors, self.nbt_incs)   # BatchNorm.num_batches_tracked, one launch
+        self.steps_done += 1
         return loss
 
     # -- public ---------------------------------------------------------------------------------

@@ -100,6 +100,14 @@ class StepContext:
         self.frozen_pack = False
         self.direct_grads = False
         self.nbt = None          # list of (tensor, increment) recorded while measuring
+        self.side = None         # second HIP stream: weight gradients run beside the data-gradient chain
+        self.keep = []           # tensors the side stream still reads (kept alive until join())
+
+    def join(self):
+        """Main stream waits for the side stream (call after backward, before the optimizer)."""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self.keep.clear()
 
     def begin_step(self):
         if self.arena is not None:
@@ -335,7 +343,19 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
 
 def wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale=None, in_shift=None, in_relu=False, groups=1):
     """Weight (and bias) gradient of one conv.  Returns (gw, gb), each None when it was accumulated straight into the
-    flat gradient buffer (StepContext.direct_grads)."""
+    flat gradient buffer (StepContext.direct_grads).  With a StepContext side stream the launches go there: nothing
+    downstream of a weight gradient runs before the optimizer, so it overlaps the latency-bound data-gradient chain."""
+    c = _ctx[0]
+    if c is not None and c.side is not None and c.direct_grads:
+        main = torch.cuda.current_stream()
+        c.side.wait_stream(main)                     # g and x are produced on the main stream
+        c.keep.append((xv, g, in_scale, in_shift))   # the caching allocator must not recycle them before join()
+        with torch.cuda.stream(c.side):
+            return _wgrad_impl(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu, groups)
+    return _wgrad_impl(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu, groups)
+
+
+def _wgrad_impl(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu, groups):
     B, Cin, H, W = xv.shape
     Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
     dt = dtype_code(xv)
@@ -361,7 +381,9 @@ def wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale=None, in_shift=None, in_
     call("sdhip_conv2d_wgrad", ptr(xv), ptr(g), ptr(acc), ptr(dbias), ptr(in_scale), ptr(in_shift),
          B, H, W, Cin, ldx, spec.Ho, spec.Wo, Cout, ldg, spec.kh, spec.kw, spec.stride, spec.dil,
          spec.pad_t, spec.pad_l, int(in_relu), groups, int(pz), dt, stream_ptr())
-    M, K, sm, sk, flip = _pack_params(spec.kind, 'fwd', Cout, Cin, T)
+    # unpack by the WEIGHT's own channel count: the activation may carry zero-padded extra channels (8-channel images)
+    wCin = weight.shape[1] if spec.kind == 'conv' else weight.shape[0]
+    M, K, sm, sk, flip = _pack_params(spec.kind, 'fwd', Cout, wCin, T)
     if tw is not None:
         call("sdhip_conv_unpack_wgrad", ptr(acc), ptr(tw), M, K, T, sm, sk, flip, 1, dt, stream_ptr())
         return None, gb

@@ -31,7 +31,7 @@ def flatten_parameters(model):
 
 class TrainStep:
     def __init__(self, model, dtype=torch.bfloat16, lr=0.0015, betas=(0.9, 0.999), eps=1e-7, use_lovasz=True,
-                 use_graph=True, world_size=1, process_group=None):
+                 use_graph=True, world_size=1, process_group=None, use_side_stream=True):
         self.model, self.dtype, self.use_lovasz = model, dtype, use_lovasz
         self.lr, self.betas, self.eps = lr, betas, eps
         self.world_size, self.pg = world_size, process_group
@@ -41,6 +41,7 @@ class TrainStep:
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.beta_pow = torch.ones(2, dtype=torch.float32, device=self.flat_p.device)
         self.use_graph = use_graph
+        self.use_side_stream = use_side_stream
         self.graph = None
         self.static = None
         self.loss = None
@@ -59,6 +60,8 @@ class TrainStep:
         self.pack_desc = torch.tensor(rows, dtype=torch.int64, device=self.flat_p.device) if rows else None
         self.ctx.frozen_pack = self.pack_desc is not None
         self.ctx.direct_grads = True
+        if self.use_side_stream:
+            self.ctx.side = torch.cuda.Stream()
         self.nbt_tensors = [t for t, _ in self.ctx.nbt]
         self.nbt_incs = [int(i) for _, i in self.ctx.nbt]
 
@@ -75,6 +78,7 @@ class TrainStep:
         outs = self.model(left.to(self.dtype), right.to(self.dtype))
         loss = ops.train_loss(outs[0], outs[1], outs[2], seg, disp, self.use_lovasz)
         loss.backward()
+        self.ctx.join()             # weight gradients ran on the side stream
         return loss.detach()
 
     def all_reduce(self):

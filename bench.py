@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     return ap.parse_args()
 
 
@@ -77,19 +78,24 @@ def kernel_roofline(dtype, B, H, W):
             "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "ms_per_launch": round(ms, 4)}
 
 
-def cpu_baseline(B, H, W, steps):
+def cpu_baseline(B, H, W, steps, threads=16):
     """The CPU oracle (a port of the reference graph to plain torch.nn) on the host cores: fwd + loss + bwd."""
     import torch.nn.functional as F
     from oracle import ref_models as R
     from pmt_learning_for_semantic_segmentation_and_disparity_amd.ops import _lovasz_softmax_torch
     from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import synthetic_batch
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(threads, avail))    # the GPU box gives one GPU's share of the host (16 cores), not the whole socket
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = R.minidsnetExt(R.CFG(), labels=2, patch_type='1dcorr').train()
     left, right, seg, disp = synthetic_batch(B, H, W, device="cpu")
     ts = []
     for i in range(steps + 1):
+        sys.stderr.write("[bench] cpu_baseline step %d/%d on %d threads\n" % (i, steps, cores)); sys.stderr.flush()
         t0 = time.time()
         o = m(left, right)
         ce = lambda y: torch.mean(torch.sum(-seg * F.log_softmax(y, 1), 1))
@@ -147,10 +153,11 @@ def main():
                                       % (a.width, a.height, a.batch, "hipGraph" if not a.no_graph else "eager"),
                           "global_batch": a.batch * world, "parallelism": "dp%d" % world},
                "loss": round(lossv, 5)}
+        sys.stderr.write("[bench] timed region done: %.3f ms/step\n" % (dt / a.steps * 1e3)); sys.stderr.flush()
         if not a.no_roofline:
             out["roofline"] = kernel_roofline(dtype, a.batch, a.height, a.width)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(2, a.height, a.width, a.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(2, a.height, a.width, a.cpu_steps, a.cpu_threads)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -54,7 +54,12 @@ struct StageSrc {
   const float* scale;      // per-channel prologue (already offset to the statistics group) or nullptr
   const float* shift;
   int relu, vec;
+  unsigned magic_iw;       // fast_div(IW): see div_magic()
 };
+
+// n / d for n < 2^16 via one v_mul_hi_u32: magic = floor(2^32 / d) + 1 (d >= 2); d == 1 is the identity.
+__device__ __forceinline__ unsigned div_magic(int d) { return d > 1 ? (unsigned)(0x100000000ULL / (unsigned)d) + 1u : 0u; }
+__device__ __forceinline__ int fast_div(int n, int d, unsigned magic) { return d > 1 ? (int)__umulhi((unsigned)n, magic) : n; }
 
 template <typename T, int NB, int NT = 256>
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const StageSrc& s, int q, int sh, int tid) {
@@ -70,7 +75,7 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const StageSrc& s
     for (int j = 0; j < NB; ++j) {
       const int i = i0 + j * NT;
       const int pix = i >> sh, c = i & ((1 << sh) - 1);
-      const int ih = pix / s.IW, iw = pix - ih * s.IW;
+      const int ih = fast_div(pix, s.IW, s.magic_iw), iw = pix - ih * s.IW;
       const int gh = s.h0 + ih, gw = s.w0 + iw;
       ch[j] = q * CK + c * V;
       off[j] = lds_off(pix, c);

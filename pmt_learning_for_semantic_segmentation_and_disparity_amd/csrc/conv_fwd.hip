@@ -24,7 +24,7 @@ struct FwdArgs {
   ConvGeom g;
   int Cin, ldx, Cout, Mpad, ldy;
   int in_relu, groups, act, accumulate;
-  int tg, vec_in, vec_out, stats_ld, nrep;
+  int tg, vec_in, vec_out, stats_ld, nrep, pf_halo, sh;
   long rep_stride;
 };
 
@@ -53,8 +53,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
   const int Tn = g.kh * g.kw;
   const int nq = (p.Cin + CK - 1) / CK;
   const int mvalid = min(BN, p.Mpad - n0);  // multiple of 16
-  unsigned char* halo = smem;
-  unsigned char* wl = smem + ((IH * IW * 128 + 15) & ~15);
+  // LDS: [halo (x2 when its loads are register-prefetched)] [weights stage buffer 0] [weights stage buffer 1]
+  const int halo_bytes = (IH * IW * 128 + 15) & ~15;
+  const int wbuf_bytes = p.tg * BN * 128;
+  unsigned char* halo0 = smem;
+  unsigned char* wl0 = smem + halo_bytes * (((TH * TW <= 64) && p.pf_halo) ? 2 : 1);
 
   f32x4 acc[NT_CO][NT_PIX];
 #pragma unroll
@@ -71,64 +74,184 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
 
   const T* xb = (const T*)p.x + (long)b * g.H * g.W * p.ldx;
   const T* wpk = (const T*)p.wp;
+  const int ntg = (Tn + p.tg - 1) / p.tg;
+  const int S = nq * ntg;   // pipeline stages: (channel chunk, tap group)
 
-  for (int q = 0; q < nq; ++q) {
-    const int cin_q = min(CK, p.Cin - q * CK);
-    const int nks = (cin_q + CK / 2 - 1) / (CK / 2);  // 64-byte k-steps in this chunk: 1 or 2
-    const int sh = nks == 2 ? 3 : 2;                  // chunks per row that carry data: 8 or 4
-    __syncthreads();                                  // previous chunk's fragments are consumed
-    // ---- stage the halo tile (global -> LDS, fused prologue) ----
-    {
-      StageSrc ss;
-      ss.base = xb; ss.H = g.H; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin; ss.h0 = ih0; ss.w0 = iw0; ss.IH = IH; ss.IW = IW;
-      ss.scale = p.in_scale ? p.in_scale + grp * p.Cin : nullptr;
-      ss.shift = p.in_scale ? p.in_shift + grp * p.Cin : nullptr;
-      ss.relu = p.in_relu; ss.vec = p.vec_in;
-      stage_tile<T, 4>(halo, ss, q, sh, tid);
+  // Software pipeline: the global loads of stage s+1 (its tap-group weights and, at a chunk boundary, its halo tile)
+  // are issued into registers BEFORE the MFMAs of stage s and committed to the other LDS buffer after them, so the
+  // L2/HBM latency hides behind the matrix work and a stage costs one barrier.
+  // PF (small 4x16 tiles only): the halo tile is register-prefetched and double-buffered too; the large 8x32 tiles
+  // stage their halo with a plain copy at chunk boundaries and spend the registers on accumulators instead.
+  constexpr bool PF = (TH * TW <= 64);
+  constexpr int HPF = PF ? 4 : 1, WPF = 4;   // 16-byte loads per lane kept in flight for the halo / the weights
+  u32x4 rh[HPF], rw[WPF];
+  const bool pf_halo = PF && p.pf_halo;
+
+  // Per-lane staging plan, computed ONCE (it does not depend on the stage): where each of this lane's 16-byte loads
+  // comes from (relative to the stage base) and where it lands in LDS.  p.sh is constant for the launch: 8 chunks per
+  // 128-byte row, or 4 when the whole reduction fits one half row (Cin <= CK/2).
+  const int sh = p.sh;
+  const unsigned magic_iw = div_magic(IW);
+  int h_src[HPF], h_lds[HPF], h_ch[HPF];   // halo: element offset inside the image (or -1), LDS byte offset, channel offset
+  if (pf_halo) {
+    const int total = (IH * IW) << sh;
+#pragma unroll
+    for (int j = 0; j < HPF; ++j) {
+      const int i = tid + j * 256;
+      h_src[j] = -1; h_lds[j] = -1; h_ch[j] = 0;
+      if (i < total) {
+        const int pix = i >> sh, c = i & ((1 << sh) - 1);
+        const int ih = fast_div(pix, IW, magic_iw), iw = pix - ih * IW;
+        const int gh = ih0 + ih, gw = iw0 + iw;
+        h_lds[j] = lds_off(pix, c);
+        h_ch[j] = c * V;
+        if (gh >= 0 && gh < g.H && gw >= 0 && gw < g.W) h_src[j] = (gh * g.W + gw) * p.ldx + c * V;
+      }
     }
+  }
+  int w_src[WPF], w_lds[WPF], w_tl[WPF];   // weights: element offset inside the stage's packed block, LDS offset, tap
+  {
+    const unsigned magic_m = div_magic(mvalid);
+#pragma unroll
+    for (int j = 0; j < WPF; ++j) {
+      const int i = tid + j * 256;
+      const int row = i >> sh, c = i & ((1 << sh) - 1);
+      const int tl = fast_div(row, mvalid, magic_m), m = row - tl * mvalid;
+      w_tl[j] = tl;
+      w_src[j] = (tl * p.Mpad + m) * CK + c * V;
+      w_lds[j] = lds_off(tl * BN + m, c);
+    }
+  }
 
-    for (int t0 = 0; t0 < Tn; t0 += p.tg) {
-      const int nt = min(p.tg, Tn - t0);
-      if (t0 > 0) __syncthreads();  // previous tap group's weights are consumed
-      // ---- stage the weights of taps [t0, t0+nt) for this channel chunk ----
-      const int wtotal = (nt * mvalid) << sh;
-      for (int i0 = tid; i0 < wtotal; i0 += 256 * 4) {
-        u32x4 raw[4]; int off[4];
+  auto halo_issue = [&](int q) {   // vector path only (host guarantees vec_in when pf_halo)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = i0 + j * 256;
-          const int row = i >> sh, c = i & ((1 << sh) - 1);
-          const int tl = row / mvalid, m = row - tl * mvalid;
-          off[j] = lds_off(tl * BN + m, c);
-          if (i < wtotal) raw[j] = *reinterpret_cast<const u32x4*>(wpk + (((long)(q * Tn + t0 + tl) * p.Mpad + n0 + m) * CK + c * V));
-        }
+    for (int j = 0; j < HPF; ++j) {
+      rh[j] = u32x4{0u, 0u, 0u, 0u};
+      if (h_src[j] >= 0 && q * CK + h_ch[j] < p.Cin)
+        rh[j] = *reinterpret_cast<const u32x4*>(xb + h_src[j] + q * CK);
+    }
+  };
+  auto halo_commit = [&](int q, unsigned char* dst) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (i0 + j * 256 < wtotal) *reinterpret_cast<u32x4*>(wl + off[j]) = raw[j];
-      }
-      __syncthreads();
-      // ---- MFMA over the taps of this group ----
-      for (int tl = 0; tl < nt; ++tl) {
-        const int t = t0 + tl;
-        const int khi = t / g.kw, kwi = t - khi * g.kw;
-        const int toff = (khi * d) * IW + kwi * d;
-        for (int ks = 0; ks < nks; ++ks) {
-          const int c = 4 * ks + lg;
-          u32x4 af[NT_CO], bf[NT_PIX];
+    for (int j = 0; j < HPF; ++j) {
+      if (h_lds[j] >= 0) {
+        u32x4 raw = rh[j];
+        if (p.in_scale && h_src[j] >= 0) {
+          const int ch0 = q * CK + h_ch[j];
+          if (ch0 < p.Cin) {   // zero padding (spatial or channel) stays zero
+            float f[V];
+            Chunk<T>::unpack(raw, f);
+            const float* sc = p.in_scale + grp * p.Cin + ch0;
+            const float* sf = p.in_shift + grp * p.Cin + ch0;
 #pragma unroll
-          for (int mi = 0; mi < NT_CO; ++mi)
-            if (mi * 16 < mvalid) af[mi] = *reinterpret_cast<const u32x4*>(wl + lds_off(tl * BN + mi * 16 + l15, c));
-#pragma unroll
-          for (int ni = 0; ni < NT_PIX; ++ni)
-            bf[ni] = *reinterpret_cast<const u32x4*>(halo + lds_off(pbase[ni] + toff, c));
-#pragma unroll
-          for (int mi = 0; mi < NT_CO; ++mi)
-            if (mi * 16 < mvalid) {
-#pragma unroll
-              for (int ni = 0; ni < NT_PIX; ++ni) Mma<T>::run(acc[mi][ni], af[mi], bf[ni]);
+            for (int e = 0; e < V; ++e) {
+              const float v = fmaf(f[e], sc[e], sf[e]);
+              f[e] = p.in_relu ? fmaxf(v, 0.f) : v;
             }
+            raw = Chunk<T>::pack(f);
+          }
         }
+        *reinterpret_cast<u32x4*>(dst + h_lds[j]) = raw;
       }
+    }
+  };
+  auto halo_sync_stage = [&](int q, unsigned char* dst) {   // big halo tiles: plain staged copy (4 loads in flight)
+    StageSrc ss;
+    ss.base = xb; ss.H = g.H; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin; ss.h0 = ih0; ss.w0 = iw0; ss.IH = IH; ss.IW = IW;
+    ss.scale = p.in_scale ? p.in_scale + grp * p.Cin : nullptr;
+    ss.shift = p.in_scale ? p.in_shift + grp * p.Cin : nullptr;
+    ss.relu = p.in_relu; ss.vec = p.vec_in; ss.magic_iw = magic_iw;
+    stage_tile<T, 4>(dst, ss, q, sh, tid);
+  };
+  auto w_issue = [&](int q, int t0) {
+    const int nt = min(p.tg, Tn - t0);
+    const T* base = wpk + ((long)(q * Tn + t0) * p.Mpad + n0) * CK;
+#pragma unroll
+    for (int j = 0; j < WPF; ++j)
+      if (w_tl[j] < nt) rw[j] = *reinterpret_cast<const u32x4*>(base + w_src[j]);
+  };
+  auto w_commit = [&](int q, int t0, unsigned char* dst) {
+    const int nt = min(p.tg, Tn - t0);
+#pragma unroll
+    for (int j = 0; j < WPF; ++j)
+      if (w_tl[j] < nt) *reinterpret_cast<u32x4*>(dst + w_lds[j]) = rw[j];
+  };
+  // Fragment addressing.  lds_off(row, c) = row*128 + ((c ^ s(row)) << 4) with s(row) = (row>>1)&7 and c = 4*ks + lg, i.e.
+  // row*128 + ((ks<<6) ^ (lg<<4) ^ (s(row)<<4)).  For the weight rows s() does not depend on the tap (tap stride BN*128 is
+  // a multiple of 16 rows), so everything but the k-step bit is hoisted out of the tap loop.
+  int a_off[NT_CO];
+#pragma unroll
+  for (int mi = 0; mi < NT_CO; ++mi) {
+    const int row = mi * 16 + l15;
+    a_off[mi] = row * 128 + ((lg << 4) ^ (((row >> 1) & 7) << 4));
+  }
+  auto compute = [&](int q, int t0, const unsigned char* halo, const unsigned char* wl) {
+    const int cq = min(CK, p.Cin - q * CK);
+    const bool two = (cq + CK / 2 - 1) / (CK / 2) == 2;   // second 64-byte k-step present (wave-uniform)
+    const int nt = min(p.tg, Tn - t0);
+    int khi = t0 / g.kw, kwi = t0 - khi * g.kw;
+    for (int tl = 0; tl < nt; ++tl) {
+      const int toff = (khi * d) * IW + kwi * d;
+      if (++kwi == g.kw) { kwi = 0; ++khi; }
+      const unsigned char* wt = wl + tl * (BN * 128);
+      int b_off[NT_PIX];
+#pragma unroll
+      for (int ni = 0; ni < NT_PIX; ++ni) {
+        const int row = pbase[ni] + toff;
+        b_off[ni] = row * 128 + ((lg << 4) ^ (((row >> 1) & 7) << 4));
+      }
+      // both k-steps' fragments are requested up front: the second k-step's LDS latency hides behind the first's MFMAs
+      u32x4 af0[NT_CO], bf0[NT_PIX], af1[NT_CO], bf1[NT_PIX];
+#pragma unroll
+      for (int mi = 0; mi < NT_CO; ++mi)
+        if (mi * 16 < mvalid) af0[mi] = *reinterpret_cast<const u32x4*>(wt + a_off[mi]);
+#pragma unroll
+      for (int ni = 0; ni < NT_PIX; ++ni) bf0[ni] = *reinterpret_cast<const u32x4*>(halo + b_off[ni]);
+      if (two) {
+#pragma unroll
+        for (int mi = 0; mi < NT_CO; ++mi)
+          if (mi * 16 < mvalid) af1[mi] = *reinterpret_cast<const u32x4*>(wt + (a_off[mi] ^ 64));
+#pragma unroll
+        for (int ni = 0; ni < NT_PIX; ++ni) bf1[ni] = *reinterpret_cast<const u32x4*>(halo + (b_off[ni] ^ 64));
+      }
+#pragma unroll
+      for (int mi = 0; mi < NT_CO; ++mi)
+        if (mi * 16 < mvalid) {
+#pragma unroll
+          for (int ni = 0; ni < NT_PIX; ++ni) Mma<T>::run(acc[mi][ni], af0[mi], bf0[ni]);
+        }
+      if (two) {
+#pragma unroll
+        for (int mi = 0; mi < NT_CO; ++mi)
+          if (mi * 16 < mvalid) {
+#pragma unroll
+            for (int ni = 0; ni < NT_PIX; ++ni) Mma<T>::run(acc[mi][ni], af1[mi], bf1[ni]);
+          }
+      }
+    }
+  };
+
+  // prologue: stage 0
+  if (pf_halo) halo_issue(0); else halo_sync_stage(0, halo0);
+  w_issue(0, 0);
+  for (int st = 0; st < S; ++st) {
+    const int q = st / ntg, t0 = (st - q * ntg) * p.tg;
+    unsigned char* halo = halo0 + ((pf_halo && (q & 1)) ? halo_bytes : 0);
+    unsigned char* wl = wl0 + (st & 1) * wbuf_bytes;
+    if (pf_halo && t0 == 0) halo_commit(q, halo);
+    w_commit(q, t0, wl);
+    __syncthreads();                      // stage st is visible; every wave has finished stage st-1
+    const int sn = st + 1;
+    int qn = 0, t0n = 0;
+    if (sn < S) {
+      qn = sn / ntg; t0n = (sn - qn * ntg) * p.tg;
+      if (pf_halo && t0n == 0) halo_issue(qn);
+      w_issue(qn, t0n);
+    }
+    compute(q, t0, halo, wl);
+    if (!pf_halo && sn < S && t0n == 0) {   // chunk boundary with a single (large) halo buffer
+      __syncthreads();
+      halo_sync_stage(qn, halo0);
     }
   }
 
@@ -250,11 +373,9 @@ int launch_bn(const FwdArgs& a, int bn, size_t lds, hipStream_t s) {
   }
 }
 
-size_t lds_need(const ConvGeom& g, int th, int tw, int rows_per_tap, int tg) {
+size_t halo_bytes_of(const ConvGeom& g, int th, int tw) {
   const int IH = (th - 1) * g.stride + (g.kh - 1) * g.dil + 1, IW = (tw - 1) * g.stride + (g.kw - 1) * g.dil + 1;
-  const size_t halo = ((size_t)IH * IW * 128 + 15) & ~(size_t)15;
-  const size_t need = halo + (size_t)tg * rows_per_tap * 128;
-  return need < 4096 ? 4096 : need;  // stats reduction scratch
+  return ((size_t)IH * IW * 128 + 15) & ~(size_t)15;
 }
 
 }  // namespace
@@ -299,22 +420,28 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
     while (bn > 32 && px_blocks * sdhip_cdiv(a.Mpad, bn) < 1024) bn >>= 1;
   }
   const int rows = a.Mpad < bn ? a.Mpad : bn;
-  const size_t kMax = 160 * 1024, kSoft = 64 * 1024;
+  const size_t kMax = 160 * 1024, kSoft = 80 * 1024;   // kSoft: two workgroups per CU
+  const int CKh = (dtype == SDHIP_BF16 ? 64 : 32);
+  const int chunks_per_row = Cin <= CKh / 2 ? 4 : 8;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int th = big ? 8 : 4, tw = big ? 32 : 16;
-    int tg = T;
-    if (lds_need(a.g, th, tw, rows, tg) > kSoft) {
-      const size_t base = lds_need(a.g, th, tw, rows, 0);
-      tg = base < kSoft ? (int)((kSoft - base) / ((size_t)rows * 128)) : 1;
-      if (tg < 1) tg = 1;
-      if (tg > T) tg = T;
-    }
-    const size_t lds = lds_need(a.g, th, tw, rows, tg);
+    const size_t halo = halo_bytes_of(a.g, th, tw);
+    const long halo_loads = (long)(halo / 128) * chunks_per_row;
+    // register-prefetched (double-buffered) halo: small tiles, at most 4 loads per lane, vector loads only
+    const int pf = !big && a.vec_in && halo_loads <= 4 * 256 && 2 * halo + 2 * (size_t)bn * 128 <= kSoft;
+    // weights: at most 4 loads per lane per stage => tg*rows*chunks_per_row <= 1024
+    int tg = 1024 / (rows * chunks_per_row);
+    if (tg < 1) tg = 1;
+    if (tg > T) tg = T;
+    const size_t hb = halo * (pf ? 2 : 1);
+    while (tg > 1 && hb + 2 * (size_t)tg * bn * 128 > kSoft) --tg;
+    size_t lds = hb + 2 * (size_t)tg * bn * 128;
+    if (lds < 4096) lds = 4096;   // stats reduction scratch
     if (lds > kMax) {
       if (big) { big = false; continue; }
       SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd: halo tile of a %dx%d kernel with dilation %d does not fit LDS", kh, kw, dil);
     }
-    a.tg = tg;
+    a.tg = tg; a.pf_halo = pf; a.sh = chunks_per_row == 4 ? 2 : 3;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SDHIP_BF16)
       return big ? launch_bn<bf16_t, 8, 32>(a, bn, lds, s) : launch_bn<bf16_t, 4, 16>(a, bn, lds, s);

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgArgs p) {
   const int s = g.stride, d = g.dil;
   const int IH = (TH - 1) * s + (g.kh - 1) * d + 1, IW = (TW - 1) * s + (g.kw - 1) * d + 1;
   const int T_ = g.kh * g.kw;
+  const unsigned magic_iw = div_magic(IW);
   int by = blockIdx.y;                       // -> (output-channel block, channel chunk, tap group)
   const int tgi = by % p.ntg; by /= p.ntg;
   const int q = by % p.nq;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgArgs p) {
     {   // X halo tile of channel chunk q (same LDS image as the forward kernel, fused prologue)
       StageSrc ss;
       ss.base = xb; ss.H = g.H; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin;
-      ss.h0 = oh0 * s - g.pad_t; ss.w0 = ow0 * s - g.pad_l; ss.IH = IH; ss.IW = IW;
+      ss.h0 = oh0 * s - g.pad_t; ss.w0 = ow0 * s - g.pad_l; ss.IH = IH; ss.IW = IW; ss.magic_iw = magic_iw;
       ss.scale = p.in_scale ? p.in_scale + grp * p.Cin : nullptr;
       ss.shift = p.in_scale ? p.in_shift + grp * p.Cin : nullptr;
       ss.relu = p.in_relu; ss.vec = p.vec_x;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgArgs p) {
     {   // dY tile of output-channel block mb (TH x TW, no halo; channels offset by m0)
       StageSrc ss;
       ss.base = yb + m0; ss.H = g.Ho; ss.W = g.Wo; ss.ld = p.lddy; ss.C = p.Cout - m0;
-      ss.h0 = oh0; ss.w0 = ow0; ss.IH = TH; ss.IW = TW;
+      ss.h0 = oh0; ss.w0 = ow0; ss.IH = TH; ss.IW = TW; ss.magic_iw = div_magic(TW);
       ss.scale = nullptr; ss.shift = nullptr; ss.relu = 0;
       ss.vec = p.vec_dy;
       stage_tile<T, 2, kThreads>(ytile, ss, 0, shy, tid);

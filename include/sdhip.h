@@ -211,6 +211,9 @@ int sdhip_ce_loss(const void* logits, int ldy, const float* target, int ldt, voi
 /* loss += weight * mean |pred - target| (nn.L1Loss, losses/multiLosses.py:141) and its gradient. */
 int sdhip_l1_loss(const void* pred, const float* target, void* grad, double* loss, long n, float weight,
                   int dtype, void* stream);
+/* y = x * mask / (1-p), mask from a counter-based hash of (*seed, layer_id, element index): applying the same call to
+ * the gradient is the backward pass (nn.Dropout(0.5) of models/aspp.py:79,95).  x/y: dense buffers of n elements. */
+int sdhip_dropout(const void* x, void* y, const long* seed, long layer_id, long n, float p, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,7 @@ SIGNATURES = {
     "sdhip_mul_bcast_bwd": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _i, _p],
     "sdhip_adam_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
     "sdhip_ce_loss": [_p, _i, _p, _i, _p, _i, _p, _l, _i, _f, _i, _p],
+    "sdhip_dropout": [_p, _p, _p, _l, _l, _f, _i, _p],
     "sdhip_l1_loss": [_p, _p, _p, _p, _l, _f, _i, _p],
     "sdhip_stats_fix": [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _i, _i, _p],
 }

@@ -24,7 +24,7 @@ struct FwdArgs {
   ConvGeom g;
   int Cin, ldx, Cout, Mpad, ldy;
   int in_relu, groups, act, accumulate;
-  int tg, vec_in, vec_out, stats_ld, nrep, pf_halo, sh;
+  int tg, vec_in, vec_out, stats_ld, nrep, pf_halo, sh, per_tap;
   long rep_stride;
 };
 
@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
   const int b = blockIdx.z;
   const int grp = p.groups > 1 ? b / (g.B / p.groups) : 0;
   const int s = g.stride, d = g.dil;
-  const int IH = (TH - 1) * s + (g.kh - 1) * d + 1, IW = (TW - 1) * s + (g.kw - 1) * d + 1;
+  // per_tap (strongly dilated kernels, e.g. ASPP's 3x3 dil 6/12): the halo tile would be mostly holes, so every tap stages
+  // just the shifted TH x TW tile instead and is treated as a 1x1 convolution.
+  const int IH = (TH - 1) * s + (p.per_tap ? 0 : (g.kh - 1) * d) + 1, IW = (TW - 1) * s + (p.per_tap ? 0 : (g.kw - 1) * d) + 1;
   const int ih0 = oh0 * s - g.pad_t, iw0 = ow0 * s - g.pad_l;
   const int Tn = g.kh * g.kw;
   const int nq = (p.Cin + CK - 1) / CK;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
     const int nt = min(p.tg, Tn - t0);
     int khi = t0 / g.kw, kwi = t0 - khi * g.kw;
     for (int tl = 0; tl < nt; ++tl) {
-      const int toff = (khi * d) * IW + kwi * d;
+      const int toff = p.per_tap ? 0 : (khi * d) * IW + kwi * d;
       if (++kwi == g.kw) { kwi = 0; ++khi; }
       const unsigned char* wt = wl + tl * (BN * 128);
       int b_off[NT_PIX];
@@ -231,6 +233,24 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
     }
   };
 
+  if (p.per_tap) {   // one stage per (chunk, tap): shifted tile + that tap's weights, no prefetch (rare, small layers)
+    for (int st = 0; st < nq * Tn; ++st) {
+      const int q = st / Tn, t = st - q * Tn;
+      const int khi = t / g.kw, kwi = t - khi * g.kw;
+      __syncthreads();
+      StageSrc ss;
+      ss.base = xb; ss.H = g.H; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin;
+      ss.h0 = ih0 + khi * d; ss.w0 = iw0 + kwi * d; ss.IH = IH; ss.IW = IW;
+      ss.scale = p.in_scale ? p.in_scale + grp * p.Cin : nullptr;
+      ss.shift = p.in_scale ? p.in_shift + grp * p.Cin : nullptr;
+      ss.relu = p.in_relu; ss.vec = p.vec_in; ss.magic_iw = magic_iw;
+      stage_tile<T, 4>(halo0, ss, q, sh, tid);
+      w_issue(q, t);
+      w_commit(q, t, wl0);
+      __syncthreads();
+      compute(q, t, halo0, wl0);
+    }
+  } else {
   // prologue: stage 0
   if (pf_halo) halo_issue(0); else halo_sync_stage(0, halo0);
   w_issue(0, 0);
@@ -253,6 +273,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
       __syncthreads();
       halo_sync_stage(qn, halo0);
     }
+  }
   }
 
   // ---- epilogue: bias / activation / accumulate / store / BN statistics ----
@@ -373,8 +394,9 @@ int launch_bn(const FwdArgs& a, int bn, size_t lds, hipStream_t s) {
   }
 }
 
-size_t halo_bytes_of(const ConvGeom& g, int th, int tw) {
-  const int IH = (th - 1) * g.stride + (g.kh - 1) * g.dil + 1, IW = (tw - 1) * g.stride + (g.kw - 1) * g.dil + 1;
+size_t halo_bytes_of(const ConvGeom& g, int th, int tw, int per_tap) {
+  const int eh = per_tap ? 0 : (g.kh - 1) * g.dil, ew = per_tap ? 0 : (g.kw - 1) * g.dil;
+  const int IH = (th - 1) * g.stride + eh + 1, IW = (tw - 1) * g.stride + ew + 1;
   return ((size_t)IH * IW * 128 + 15) & ~(size_t)15;
 }
 
@@ -425,12 +447,13 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   const int chunks_per_row = Cin <= CKh / 2 ? 4 : 8;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int th = big ? 8 : 4, tw = big ? 32 : 16;
-    const size_t halo = halo_bytes_of(a.g, th, tw);
+    const int per_tap = (kh > 1 || kw > 1) && dil >= 4;   // halo would be >= 4x the tile in each direction's holes
+    const size_t halo = halo_bytes_of(a.g, th, tw, per_tap);
     const long halo_loads = (long)(halo / 128) * chunks_per_row;
     // register-prefetched (double-buffered) halo: small tiles, at most 4 loads per lane, vector loads only
-    const int pf = !big && a.vec_in && halo_loads <= 4 * 256 && 2 * halo + 2 * (size_t)bn * 128 <= kSoft;
+    const int pf = !per_tap && !big && a.vec_in && halo_loads <= 4 * 256 && 2 * halo + 2 * (size_t)bn * 128 <= kSoft;
     // weights: at most 4 loads per lane per stage => tg*rows*chunks_per_row <= 1024
-    int tg = 1024 / (rows * chunks_per_row);
+    int tg = per_tap ? 1 : 1024 / (rows * chunks_per_row);
     if (tg < 1) tg = 1;
     if (tg > T) tg = T;
     const size_t hb = halo * (pf ? 2 : 1);
@@ -441,7 +464,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
       if (big) { big = false; continue; }
       SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd: halo tile of a %dx%d kernel with dilation %d does not fit LDS", kh, kw, dil);
     }
-    a.tg = tg; a.pf_halo = pf; a.sh = chunks_per_row == 4 ? 2 : 3;
+    a.tg = tg; a.pf_halo = pf; a.sh = chunks_per_row == 4 ? 2 : 3; a.per_tap = per_tap;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SDHIP_BF16)
       return big ? launch_bn<bf16_t, 8, 32>(a, bn, lds, s) : launch_bn<bf16_t, 4, 16>(a, bn, lds, s);

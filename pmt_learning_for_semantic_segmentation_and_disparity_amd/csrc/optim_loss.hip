@@ -141,3 +141,35 @@ extern "C" int sdhip_l1_loss(const void* pred, const float* target, void* grad, 
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }
+
+// ---- dropout (nn.Dropout in ASPP, models/aspp.py:79,95): counter-based hash RNG, so the backward pass regenerates
+// the mask from (seed, layer id, element index) instead of storing it; the seed lives in device memory and is advanced
+// once per step by the training harness, which keeps the step graph-replayable.
+namespace {
+__device__ __forceinline__ unsigned int hash32(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (unsigned int)x;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, const long* __restrict__ seed,
+                                                      long layer, long n, float p, float scale) {
+  const unsigned long long s = (unsigned long long)seed[0] * 0x9E3779B97F4A7C15ULL + (unsigned long long)layer * 0xD1B54A32D192ED03ULL;
+  const unsigned int thr = (unsigned int)((double)p * 4294967296.0);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const bool keep = hash32(s + (unsigned long long)i) >= thr;
+    Elem<T>::st(y + i, keep ? Elem<T>::ld(x + i) * scale : 0.f);
+  }
+}
+}  // namespace
+
+extern "C" int sdhip_dropout(const void* x, void* y, const long* seed, long layer_id, long n, float p, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(x && y && seed && n > 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "dropout: unknown dtype %d", dtype);
+  const float scale = 1.f / (1.f - p);
+  if (dtype == SDHIP_F32)
+    hipLaunchKernelGGL(dropout_kernel<float>, grid_for(n), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, seed, layer_id, n, p, scale);
+  else
+    hipLaunchKernelGGL(dropout_kernel<bf16_t>, grid_for(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, seed, layer_id, n, p, scale);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}

@@ -867,3 +867,56 @@ class _TrainLossFn(torch.autograd.Function):
 def train_loss(seg1, disp, seg2, seg_target, disp_target, use_lovasz=True):
     """seg_target: one-hot f32 (B,C,H,W); disp_target: f32 (B,1,H,W)."""
     return _TrainLossFn.apply(seg1, disp, seg2, seg_target, disp_target, use_lovasz)
+
+
+# ============================================================================ dropout / global average pool
+_rng = {"seed": None, "layers": 0}
+
+
+def rng_seed_tensor(device):
+    """Device-resident dropout seed (advance it once per step: `ops.rng_seed_tensor(dev).add_(1)`)."""
+    if _rng["seed"] is None or _rng["seed"].device != torch.device(device):
+        _rng["seed"] = torch.full((1,), 0x5DEECE66D, dtype=torch.int64, device=device)
+    return _rng["seed"]
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, layer_id):
+        _require_gpu(x)
+        B, C, H, W = x.shape
+        xv, ld = nhwc_view(x)
+        if ld != C:
+            xv = xv.contiguous(memory_format=torch.channels_last)
+        y = empty_nhwc(B, C, H, W, x.dtype, x.device)
+        seed = rng_seed_tensor(x.device)
+        call("sdhip_dropout", ptr(xv), ptr(y), ptr(seed), layer_id, x.numel(), p, dtype_code(x), stream_ptr())
+        ctx.cfg = (p, layer_id)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        p, layer_id = ctx.cfg
+        B, C, H, W = gy.shape
+        g, ld = nhwc_view(gy)
+        if ld != C:
+            g = g.contiguous(memory_format=torch.channels_last)
+        gx = empty_nhwc(B, C, H, W, gy.dtype, gy.device)
+        call("sdhip_dropout", ptr(g), ptr(gx), ptr(rng_seed_tensor(gy.device)), layer_id, gy.numel(), p, dtype_code(gy), stream_ptr())
+        return gx, None, None
+
+
+def dropout(x, p, training, layer_id):
+    if not training or p == 0.0:
+        return x
+    return _DropoutFn.apply(x, float(p), int(layer_id))
+
+
+def global_avg_pool(x):
+    """nn.AdaptiveAvgPool2d((1,1)): gcd(H,W)-sized square average pools (equal windows, so the mean of the window means is
+    the global mean), then the mean of the few remaining cells (a (B,C,h,w) tensor with h*w tiny)."""
+    import math
+    B, C, H, W = x.shape
+    k = math.gcd(H, W)
+    y = avgpool(x, k) if k > 1 else x
+    return y.mean((2, 3), keepdim=True) if y.shape[2] * y.shape[3] > 1 else y

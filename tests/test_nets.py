@@ -149,3 +149,45 @@ def test_hip_minidsnet_matches_golden(tag, patch, mode):
         n5 = m.resnet_features.resnet_features.norm5
         np.testing.assert_allclose(n5.running_mean.cpu().numpy(), gold[p + ".rm.norm5"], rtol=1e-3, atol=1e-4)
         np.testing.assert_allclose(n5.running_var.cpu().numpy(), gold[p + ".rv.norm5"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,cin", [("aspp_a1", 128), ("aspp_a3", 512)])
+def test_hip_aspp_matches_golden(tag, cin):
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.aspp import build_aspp
+    from oracle.detweights import randn_input
+    gold = np.load(os.path.join(GDIR, "backbone.npz"))
+    m = fill_state_dict(build_aspp('densenet_a1' if tag == "aspp_a1" else 'densenet_a3', 32), 23).cuda().eval()
+    x = randn_input(23, tag, (2, cin, 16, 24)).cuda().requires_grad_(True)
+    y = m(x)
+    y.backward(randn_input(24, tag, tuple(y.shape)).cuda())
+    _check(gold, tag + ".y", y, 1e-3, stride=2)
+    _check(gold, tag + ".gx", x.grad, 2e-3, stride=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,aspp", [("mini_a1", 1), ("mini_a2", 2)])
+def test_hip_minidsnet_aspp_eval_matches_golden(tag, aspp):
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    gold = np.load(os.path.join(GDIR, "nets.npz"))
+    a, b, seg, disp = _net_inputs()
+    m = fill_state_dict(N.minidsnetExt(R.CFG(aspp=aspp), labels=2, patch_type='1dcorr'), 31).cuda().eval()
+    outs = m(a.cuda(), b.cuda())
+    loss = train_loss(outs, seg.cuda(), disp.cuda())
+    loss.backward()
+    for i, name in enumerate(("seg1", "disp", "seg2")):
+        _check(gold, "%s.eval.%s" % (tag, name), outs[i], 1e-3)
+    want = float(gold[tag + ".eval.loss"])
+    assert abs(loss.item() - want) <= 1e-3 * max(1.0, abs(want))
+
+
+@pytest.mark.gpu
+def test_hip_aspp_train_dropout_statistics():
+    """Train mode: Dropout(0.5) keeps about half of the activations, scales them by 2, and the backward mask matches."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    x = torch.ones(2, 64, 16, 32, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.dropout(x, 0.5, True, 7)
+    y.sum().backward()
+    kept = float((y != 0).float().mean())
+    assert 0.45 < kept < 0.55 and float(y.max()) == 2.0
+    assert torch.equal(x.grad != 0, y != 0)

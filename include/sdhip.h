@@ -214,6 +214,14 @@ int sdhip_l1_loss(const void* pred, const float* target, void* grad, double* los
 /* y = x * mask / (1-p), mask from a counter-based hash of (*seed, layer_id, element index): applying the same call to
  * the gradient is the backward pass (nn.Dropout(0.5) of models/aspp.py:79,95).  x/y: dense buffers of n elements. */
 int sdhip_dropout(const void* x, void* y, const long* seed, long layer_id, long n, float p, int dtype, void* stream);
+/* Lovasz-softmax (util/lovasz_losses.py:153-199: classes='present', per_image=False, ignore=None) on
+ * softmax(logits) with labels = argmax(target one-hot), as called at losses/multiLosses.py:70-72.
+ * loss += weight * mean_{present c} dot(sort_desc |fg_c - p_c|, lovasz_grad(fg sorted)); grad (if non-NULL) is
+ * ACCUMULATED (+=) with the gradient w.r.t. the logits.  workspace: sdhip_lovasz_workspace_bytes(npix, C) bytes. */
+long sdhip_lovasz_workspace_bytes(long npix, int C);
+int sdhip_lovasz_softmax(const void* logits, int ldy, const float* target, int ldt, void* grad, int ldg,
+                         double* loss, long npix, int C, float weight, void* workspace, long workspace_bytes,
+                         int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,15 +59,22 @@ SIGNATURES = {
     "sdhip_adam_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
     "sdhip_ce_loss": [_p, _i, _p, _i, _p, _i, _p, _l, _i, _f, _i, _p],
     "sdhip_dropout": [_p, _p, _p, _l, _l, _f, _i, _p],
+    "sdhip_lovasz_softmax": [_p, _i, _p, _i, _p, _i, _p, _l, _i, _f, _p, _l, _i, _p],
     "sdhip_l1_loss": [_p, _p, _p, _p, _l, _f, _i, _p],
     "sdhip_stats_fix": [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _i, _i, _p],
 }
+_lib.sdhip_lovasz_workspace_bytes.argtypes = [_l, _i]
+_lib.sdhip_lovasz_workspace_bytes.restype = _l
 _lib.sdhip_conv_packed_elems.argtypes = [_i, _i, _i, _i]
 _lib.sdhip_conv_packed_elems.restype = _l
 for _name, _args in SIGNATURES.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
     _fn.restype = _i
+
+
+def lovasz_workspace_bytes(npix, C):
+    return _lib.sdhip_lovasz_workspace_bytes(npix, C)
 
 
 def packed_elems(M, K, T, dt):

@@ -800,8 +800,8 @@ def mul_bcast(a, m):
 
 # ============================================================================ losses of the timed step
 def _lovasz_softmax_torch(logits, labels_onehot):
-    """Lovasz-softmax (util/lovasz_losses.py:153-199, classes='present') on the GPU with ATen sort/cumsum.
-    TRANSITIONAL: the only piece of the step that is not a hand-written kernel yet."""
+    """Lovasz-softmax (util/lovasz_losses.py:153-199, classes='present') in plain torch ops — used by bench.py's CPU
+    baseline and as the checker of the native kernel in the tests; the product path is sdhip_lovasz_softmax."""
     B, C, H, W = logits.shape
     p = torch.softmax(logits.float(), 1).permute(0, 2, 3, 1).reshape(-1, C)
     fg_all = labels_onehot.permute(0, 2, 3, 1).reshape(-1, C)
@@ -821,6 +821,9 @@ def _lovasz_softmax_torch(logits, labels_onehot):
         total = total + has * torch.dot(err_s, jac.detach())
         present = present + has
     return total / present.clamp_min(1.0)
+
+
+_lovasz_ws = {}
 
 
 class _TrainLossFn(torch.autograd.Function):
@@ -847,14 +850,17 @@ class _TrainLossFn(torch.autograd.Function):
             raise _lib.SdhipError("disparity tensors must be dense (B,1,H,W)")
         gd = torch.empty_like(dv)
         call("sdhip_l1_loss", ptr(dv), ptr(disp_t), ptr(gd), ptr(loss), npix, 1.0, dt, stream_ptr())
+        if use_lovasz:   # added onto the CE gradient of seg2 in place
+            s2, ld2 = nhwc_view(seg2)
+            nbytes = _lib.lovasz_workspace_bytes(npix, C)
+            key = (npix, C, str(seg1.device))
+            ws = _lovasz_ws.get(key)
+            if ws is None or ws.numel() < nbytes:
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=seg1.device)
+                _lovasz_ws[key] = ws
+            call("sdhip_lovasz_softmax", ptr(s2), ld2, ptr(tv), ldt, ptr(grads[1]), C, ptr(loss), npix, C, 1.0, ptr(ws),
+                 ws.numel(), dt, stream_ptr())
         total = loss
-        if use_lovasz:
-            with torch.enable_grad():
-                s2 = seg2.detach().requires_grad_(True)
-                lov = _lovasz_softmax_torch(s2, seg_t)
-                (g2,) = torch.autograd.grad(lov, s2)
-            grads[1] = grads[1] + g2.to(grads[1].dtype)
-            total = loss + lov.detach().double()
         ctx.save_for_backward(grads[0], gd, grads[1])
         return total.float()
 

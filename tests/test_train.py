@@ -78,3 +78,52 @@ def test_adam_kernel_matches_torch():
         ref.grad = gi.clone(); opt.step()
         call("sdhip_adam_step", ptr(p), ptr(gi), ptr(m), ptr(v), ptr(bp), n, 0.0015, 0.9, 0.999, 1e-7, 0.0, 1.0, stream_ptr())
     assert float((p - ref.detach()).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_train_loss_matches_reference_formulas(dtype, tol):
+    """CE + CE + Lovasz + L1 value and gradients vs the plain-torch restatement of the reference formulas
+    (util/utilTorchLoss.py:373-378, util/lovasz_losses.py:153-199, losses/multiLosses.py:70-72,141)."""
+    import torch.nn.functional as F
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    torch.manual_seed(3)
+    B, C, H, W = 2, 2, 64, 96
+    seg1 = torch.randn(B, C, H, W); seg2 = torch.randn(B, C, H, W); disp = torch.rand(B, 1, H, W) * 8
+    lab = torch.randint(0, C, (B, H, W))
+    seg_t = F.one_hot(lab, C).permute(0, 3, 1, 2).float().contiguous(); disp_t = torch.rand(B, 1, H, W) * 8
+    if dtype == torch.bfloat16:
+        seg1, seg2, disp = (t.bfloat16().float() for t in (seg1, seg2, disp))
+    r = [t.clone().requires_grad_(True) for t in (seg1, disp, seg2)]
+    ce = lambda y: torch.mean(torch.sum(-seg_t * F.log_softmax(y, 1), 1))
+    want = ce(r[0]) + ce(r[2]) + ops._lovasz_softmax_torch(r[2], seg_t) + F.l1_loss(r[1], disp_t)
+    want.backward()
+    g = [t.cuda().to(dtype).requires_grad_(True) for t in (seg1, disp, seg2)]
+    got = ops.train_loss(g[0], g[1], g[2], seg_t.cuda(), disp_t.cuda(), True)
+    got.backward()
+    assert abs(float(got) - float(want)) <= tol * max(1.0, abs(float(want)))
+    for a, b in zip(g, r):
+        scale = float(b.grad.abs().max())
+        assert float((a.grad.float().cpu() - b.grad).abs().max()) <= max(tol, 2e-3) * scale
+
+
+@pytest.mark.gpu
+def test_lovasz_single_class_present():
+    """classes='present': a class with no pixel is skipped (and the mean runs over the present ones only)."""
+    import torch.nn.functional as F
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    torch.manual_seed(4)
+    B, C, H, W = 1, 3, 32, 32
+    seg = torch.randn(B, C, H, W)
+    lab = torch.zeros(B, H, W, dtype=torch.long); lab[:, :, 16:] = 2          # class 1 absent
+    seg_t = F.one_hot(lab, C).permute(0, 3, 1, 2).float().contiguous()
+    zero = torch.zeros(B, 1, H, W)
+    r = seg.clone().requires_grad_(True)
+    ce = lambda y: torch.mean(torch.sum(-seg_t * F.log_softmax(y, 1), 1))
+    want = 2 * ce(r) + ops._lovasz_softmax_torch(r, seg_t)
+    want.backward()
+    g1 = seg.cuda().requires_grad_(True); g2 = seg.cuda().requires_grad_(True)
+    got = ops.train_loss(g1, zero.cuda().requires_grad_(True), g2, seg_t.cuda(), zero.cuda(), True)
+    got.backward()
+    assert abs(float(got) - float(want)) < 1e-4
+    assert float(((g1.grad + g2.grad).cpu() - r.grad).abs().max()) < 1e-5

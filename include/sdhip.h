@@ -103,6 +103,9 @@ int sdhip_conv_unpack_wgrad(const float* acc, float* grad, int M, int K, int T,
  *            of adds into one 256-byte line serialise; consumers sum the replicas); the kernel ADDS sum(y) and sum(y^2) over pixels
  *            (of the stored, rounded values) — the batch statistics of the BatchNorm that follows;
  *   act    : 0 none, 1 ReLU, 2 sigmoid;  accumulate != 0: y += result.
+ * 3-D convolutions (nn.Conv3d / nn.ConvTranspose3d of models_psmnet/submodule.py:16-19, stackhourglass.py:10-50):
+ * a volume is [B][D][H][W][C]; (D, Do, kd, sd, pad_d) describe the depth axis and the packed weights gain a leading
+ * depth-tap dimension [kd][q][t][m][c] (pack each depth tap with sdhip_conv_pack_weights).  2-D: D=Do=kd=sd=1, pad_d=0.
  * (pad_t, pad_l) is the top/left padding; bottom/right padding is implied by (Ho, Wo)
  * (TF-"same" padding of models/torch_model.py:276-281 is asymmetric for stride 2). */
 int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
@@ -111,6 +114,7 @@ int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                      int B, int H, int W, int Cin, int ldx,
                      int Ho, int Wo, int Cout, int ldy,
                      int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                     int D, int Do, int kd, int sd, int pad_d,
                      int in_relu, int groups, int act, int accumulate,
                      int dtype, void* stream);
 /* prezeroed != 0: the caller already zeroed dw_packed / dbias (one arena memset per step instead of one per call).
@@ -120,6 +124,7 @@ int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* d
                        int B, int H, int W, int Cin, int ldx,
                        int Ho, int Wo, int Cout, int lddy,
                        int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                       int D, int Do, int kd, int sd, int pad_d,
                        int in_relu, int groups, int prezeroed, int dtype, void* stream);
 /* Pack many weights in one launch: desc = ndesc rows of 8 int64 {src ptr, dst ptr, M, K, T, stride_m, stride_k, flip}
  * in device memory (same layout rules as sdhip_conv_pack_weights). */
@@ -222,6 +227,26 @@ long sdhip_lovasz_workspace_bytes(long npix, int C);
 int sdhip_lovasz_softmax(const void* logits, int ldy, const float* target, int ldt, void* grad, int ldg,
                          double* loss, long npix, int C, float weight, void* workspace, long workspace_bytes,
                          int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * PSMNet pieces (models_psmnet/stackhourglass.py:110-119,138-155; submodule.py:56-64).
+ * ------------------------------------------------------------------------- */
+/* scatter != 0: dst[n, d*sd, h*s, w*s, :] = src[n,d,h,w,:] into a zeroed (here) dense tensor of extent
+ * ((D-1)*sd+1, (H-1)*s+1, (W-1)*s+1); scatter == 0: the gather back (dst dense-small, src stuffed).
+ * Stride-s transposed convolutions and strided data gradients run as stride-1 convolutions over the stuffed tensor. */
+int sdhip_stuff(const void* src, int ld_src, void* dst, int ld_dst, int N, int D, int H, int W, int C,
+                int sd, int s, int scatter, int dtype, void* stream);
+/* vol[b,i,h,w,0:C] = left[b,h,w,:], vol[b,i,h,w,C:2C] = right[b,h,w-i,:] for w >= i, else 0 (vol dense [B][D][H][W][2C]). */
+int sdhip_cost_volume_fwd(const void* left, const void* right, int ld, void* vol, int B, int D, int H, int W, int C,
+                          int dtype, void* stream);
+int sdhip_cost_volume_bwd(const void* gvol, void* gleft, void* gright, int ld, int B, int D, int H, int W, int C,
+                          int dtype, void* stream);
+/* pred[b,h,w] = sum_d softmax_d(trilinear_upsample(cost)[b,d,h,w]) * d, cost [B][D4][H4][W4] -> (Dout,H,W),
+ * align_corners=False; the (B,Dout,H,W) tensor is never materialised.  bwd: gcost_f32 is a [B*D4*H4*W4] f32 scratch. */
+int sdhip_softargmin_fwd(const void* cost, void* pred, int B, int D4, int H4, int W4, int Dout, int H, int W,
+                         int dtype, void* stream);
+int sdhip_softargmin_bwd(const void* cost, const void* gpred, void* gcost, float* gcost_f32, int B, int D4, int H4, int W4,
+                         int Dout, int H, int W, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -212,14 +212,47 @@ def gen_nets():
     save("nets", **arrays)
 
 
+def gen_psmnet():
+    import importlib
+    SH = importlib.import_module("models_psmnet.stackhourglass")   # (the package re-exports the class under this name)
+    arrays = {}
+    for mode in ("train", "eval"):
+        ref = fill_state_dict(SH.PSMNet(64), 41)
+        ref.train() if mode == "train" else ref.eval()
+        a, b = rand_input(41, "left", (2, 3, 256, 256)), rand_input(41, "right", (2, 3, 256, 256))
+        disp = rand_input(41, "disp", (2, 256, 256), 0.0, 40.0)
+        outs = ref(a, b)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        loss = sum(F.l1_loss(o, disp) for o in outs) / len(outs)   # build-defined PSMNet loss: mean L1 of the predictions
+        loss.backward()
+        p = "psm64.%s" % mode
+        for i, o in enumerate(outs):
+            arrays.update(flat("%s.pred%d" % (p, i), sample(o, 8)))
+        arrays["%s.loss" % p] = np.float64(loss.item())
+        for k, v in grad_norms(ref).items():
+            arrays["%s.gnorm.%s" % (p, k)] = v
+        mine = R.PSMNet(64)
+        mine.load_state_dict(fill_state_dict(SH.PSMNet(64), 41).state_dict() if mode == "train" else ref.state_dict())
+        mine.train() if mode == "train" else mine.eval()
+        mo = mine(a, b)
+        mo = mo if isinstance(mo, tuple) else (mo,)
+        for x, y in zip(mo, outs):
+            err = float((x - y).abs().max())
+            assert err < 1e-3, (mode, err)
+        print("psmnet", mode, "oracle==reference, loss", loss.item())
+    save("psmnet", **arrays)
+
+
 if __name__ == "__main__":
     _install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "backbone", "nets"]
+    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet"]
     if "ops" in which:
         gen_ops()
     if "backbone" in which:
         gen_backbone()
     if "nets" in which:
         gen_nets()
+    if "psmnet" in which:
+        gen_psmnet()

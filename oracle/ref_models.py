@@ -479,3 +479,131 @@ class minidsnetExt(nn.Module):
                 s = self.convOutput2(seg2)
                 seg2 = (self.convOutput(seg2) + s) if self.convDeconvOut == 2 else s
         return seg1, disp, seg2, disp
+
+
+# --------------------------------------------------------------------------- PSMNet (models_psmnet/*)
+def _cb2(cin, cout, k, s, pad, dil):
+    """models_psmnet/submodule.py:10-13."""
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride=s, padding=dil if dil > 1 else pad, dilation=dil, bias=False),
+                         nn.BatchNorm2d(cout))
+
+
+def _cb3(cin, cout, k, s, pad):
+    """models_psmnet/submodule.py:16-19."""
+    return nn.Sequential(nn.Conv3d(cin, cout, k, padding=pad, stride=s, bias=False), nn.BatchNorm3d(cout))
+
+
+class BasicBlock(nn.Module):
+    """models_psmnet/submodule.py:21-46."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride, downsample, pad, dilation):
+        super().__init__()
+        self.conv1 = nn.Sequential(_cb2(inplanes, planes, 3, stride, pad, dilation), nn.ReLU(inplace=True))
+        self.conv2 = _cb2(planes, planes, 3, 1, pad, dilation)
+        self.downsample, self.stride = downsample, stride
+
+    def forward(self, x):
+        out = self.conv2(self.conv1(x))
+        return out + (self.downsample(x) if self.downsample is not None else x)
+
+
+class feature_extraction(nn.Module):
+    """models_psmnet/submodule.py:66-141."""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 32
+        self.firstconv = nn.Sequential(_cb2(3, 32, 3, 2, 1, 1), nn.ReLU(inplace=True), _cb2(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
+                                       _cb2(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True))
+        self.layer1 = self._make(32, 3, 1, 1, 1)
+        self.layer2 = self._make(64, 16, 2, 1, 1)
+        self.layer3 = self._make(128, 3, 1, 1, 1)
+        self.layer4 = self._make(128, 3, 1, 1, 2)
+        for j, p in enumerate((64, 32, 16, 8)):
+            setattr(self, 'branch%d' % (j + 1), nn.Sequential(nn.AvgPool2d((p, p), stride=(p, p)), _cb2(128, 32, 1, 1, 0, 1), nn.ReLU(inplace=True)))
+        self.lastconv = nn.Sequential(_cb2(320, 128, 3, 1, 1, 1), nn.ReLU(inplace=True), nn.Conv2d(128, 32, 1, bias=False))
+
+    def _make(self, planes, blocks, stride, pad, dilation):
+        ds = None
+        if stride != 1 or self.inplanes != planes:
+            ds = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride=stride, bias=False), nn.BatchNorm2d(planes))
+        layers = [BasicBlock(self.inplanes, planes, stride, ds, pad, dilation)]
+        self.inplanes = planes
+        layers += [BasicBlock(planes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        raw = self.layer2(self.layer1(self.firstconv(x)))
+        skip = self.layer4(self.layer3(raw))
+        br = [F.interpolate(getattr(self, 'branch%d' % j)(skip), skip.shape[2:], mode='bilinear') for j in (1, 2, 3, 4)]
+        return self.lastconv(torch.cat((raw, skip, br[3], br[2], br[1], br[0]), 1))
+
+
+class hourglass(nn.Module):
+    """models_psmnet/stackhourglass.py:10-50."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = nn.Sequential(_cb3(c, c * 2, 3, 2, 1), nn.ReLU(inplace=True))
+        self.conv2 = _cb3(c * 2, c * 2, 3, 1, 1)
+        self.conv3 = nn.Sequential(_cb3(c * 2, c * 2, 3, 2, 1), nn.ReLU(inplace=True))
+        self.conv4 = nn.Sequential(_cb3(c * 2, c * 2, 3, 1, 1), nn.ReLU(inplace=True))
+        self.conv5 = nn.Sequential(nn.ConvTranspose3d(c * 2, c * 2, 3, padding=1, output_padding=1, stride=2, bias=False), nn.BatchNorm3d(c * 2))
+        self.conv6 = nn.Sequential(nn.ConvTranspose3d(c * 2, c, 3, padding=1, output_padding=1, stride=2, bias=False), nn.BatchNorm3d(c))
+
+    def forward(self, x, presqu, postsqu):
+        out = self.conv1(x)
+        pre = self.conv2(out)
+        pre = F.relu(pre + postsqu) if postsqu is not None else F.relu(pre)
+        out = self.conv4(self.conv3(pre))
+        post = F.relu(self.conv5(out) + (presqu if presqu is not None else pre))
+        return self.conv6(post), pre, post
+
+
+class PSMNet(nn.Module):
+    """models_psmnet/stackhourglass.py:52-160 (device-agnostic: no hard-coded .cuda())."""
+
+    def __init__(self, maxdisp):
+        super().__init__()
+        self.maxdisp = maxdisp
+        self.feature_extraction = feature_extraction()
+        self.dres0 = nn.Sequential(_cb3(64, 32, 3, 1, 1), nn.ReLU(inplace=True), _cb3(32, 32, 3, 1, 1), nn.ReLU(inplace=True))
+        self.dres1 = nn.Sequential(_cb3(32, 32, 3, 1, 1), nn.ReLU(inplace=True), _cb3(32, 32, 3, 1, 1))
+        self.dres2, self.dres3, self.dres4 = hourglass(32), hourglass(32), hourglass(32)
+        for j in (1, 2, 3):
+            setattr(self, 'classif%d' % j, nn.Sequential(_cb3(32, 32, 3, 1, 1), nn.ReLU(inplace=True), nn.Conv3d(32, 1, 3, padding=1, bias=False)))
+
+    def _regress(self, cost, size):
+        c = F.interpolate(cost, [self.maxdisp, size[0], size[1]], mode='trilinear').squeeze(1)
+        p = F.softmax(c, 1)
+        d = torch.arange(self.maxdisp, dtype=p.dtype, device=p.device).view(1, -1, 1, 1)
+        return torch.sum(p * d, 1)
+
+    def forward(self, left, right):
+        ref, tgt = self.feature_extraction(left), self.feature_extraction(right)
+        B, C, H, W = ref.shape
+        D = self.maxdisp // 4
+        cost = ref.new_zeros(B, C * 2, D, H, W)
+        for i in range(D):
+            if i > 0:
+                cost[:, :C, i, :, i:] = ref[:, :, :, i:]
+                cost[:, C:, i, :, i:] = tgt[:, :, :, :-i]
+            else:
+                cost[:, :C, i] = ref
+                cost[:, C:, i] = tgt
+        cost0 = self.dres0(cost)
+        cost0 = self.dres1(cost0) + cost0
+        out1, pre1, post1 = self.dres2(cost0, None, None)
+        out1 = out1 + cost0
+        out2, pre2, post2 = self.dres3(out1, pre1, post1)
+        out2 = out2 + cost0
+        out3, pre3, post3 = self.dres4(out2, pre1, post2)
+        out3 = out3 + cost0
+        cost1 = self.classif1(out1)
+        cost2 = self.classif2(out2) + cost1
+        cost3 = self.classif3(out3) + cost2
+        pred3 = self._regress(cost3, left.shape[2:])
+        if self.training:
+            return self._regress(cost1, left.shape[2:]), self._regress(cost2, left.shape[2:]), pred3
+        return pred3

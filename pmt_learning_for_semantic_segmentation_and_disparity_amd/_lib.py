@@ -39,8 +39,8 @@ SIGNATURES = {
     "sdhip_corr_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_conv_pack_weights": [_p, _p, _i, _i, _i, _l, _l, _i, _i, _p],
     "sdhip_conv_unpack_wgrad": [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p],
-    "sdhip_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 22 + [_p],
-    "sdhip_conv2d_wgrad": [_p, _p, _p, _p, _p, _p] + [_i] * 19 + [_p],
+    "sdhip_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 27 + [_p],
+    "sdhip_conv2d_wgrad": [_p, _p, _p, _p, _p, _p] + [_i] * 24 + [_p],
     "sdhip_conv_pack_batch": [_p, _i, _i, _p],
     "sdhip_channel_stats": [_p, _i, _p, _i, _i, _l, _i, _i, _i, _i, _p],
     "sdhip_stats_replica_sum": [_p, _p, _i, _i, _i, _i, _i, _p],
@@ -60,6 +60,11 @@ SIGNATURES = {
     "sdhip_ce_loss": [_p, _i, _p, _i, _p, _i, _p, _l, _i, _f, _i, _p],
     "sdhip_dropout": [_p, _p, _p, _l, _l, _f, _i, _p],
     "sdhip_lovasz_softmax": [_p, _i, _p, _i, _p, _i, _p, _l, _i, _f, _p, _l, _i, _p],
+    "sdhip_stuff": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_cost_volume_fwd": [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_cost_volume_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_softargmin_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_softargmin_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_l1_loss": [_p, _p, _p, _p, _l, _f, _i, _p],
     "sdhip_stats_fix": [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _i, _i, _p],
 }

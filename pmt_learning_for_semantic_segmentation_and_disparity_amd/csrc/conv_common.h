@@ -41,6 +41,10 @@ struct ConvGeom {
   int B, H, W;        // input  spatial
   int Ho, Wo;         // output spatial
   int kh, kw, stride, dil, pad_t, pad_l;
+  // third (depth) axis of the 3-D convolutions of the PSMNet cost-volume network (models_psmnet/submodule.py:16-19):
+  // a volume is stored [B][D][H][W][C]; the depth taps are folded into the channel-chunk loop (chunk = (kd, 128-byte
+  // channel chunk)), so one launch accumulates all kd*kh*kw taps in registers.  2-D convs: D = Do = kd = sd = 1, pad_d = 0.
+  int D, Do, kd, sd, pad_d;
 };
 
 // Stage one input tile (npx = IH*IW pixels, `1<<sh` 16-byte chunks per pixel of channel chunk q) into LDS with

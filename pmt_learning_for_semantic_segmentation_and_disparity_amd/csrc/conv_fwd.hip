@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
   const int tiles_w = (g.Wo + TW - 1) / TW;
   const int oh0 = (blockIdx.x / tiles_w) * TH, ow0 = (blockIdx.x % tiles_w) * TW;
   const int n0 = blockIdx.y * BN;
-  const int b = blockIdx.z;
+  const int b = blockIdx.z / g.Do, dz = blockIdx.z - b * g.Do;   // image = (batch, output depth slice)
   const int grp = p.groups > 1 ? b / (g.B / p.groups) : 0;
   const int s = g.stride, d = g.dil;
   // per_tap (strongly dilated kernels, e.g. ASPP's 3x3 dil 6/12): the halo tile would be mostly holes, so every tap stages
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
   const int IH = (TH - 1) * s + (p.per_tap ? 0 : (g.kh - 1) * d) + 1, IW = (TW - 1) * s + (p.per_tap ? 0 : (g.kw - 1) * d) + 1;
   const int ih0 = oh0 * s - g.pad_t, iw0 = ow0 * s - g.pad_l;
   const int Tn = g.kh * g.kw;
-  const int nq = (p.Cin + CK - 1) / CK;
+  const int nq = (p.Cin + CK - 1) / CK;     // channel chunks per depth tap; the chunk loop runs over kd*nq "chunks"
+  const int nqq = g.kd * nq;
   const int mvalid = min(BN, p.Mpad - n0);  // multiple of 16
   // LDS: [halo (x2 when its loads are register-prefetched)] [weights stage buffer 0] [weights stage buffer 1]
   const int halo_bytes = (IH * IW * 128 + 15) & ~15;
@@ -74,10 +75,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
     pbase[ni] = ((pt / TWT) * s) * IW + ((pt % TWT) * 16 + l15) * s;
   }
 
-  const T* xb = (const T*)p.x + (long)b * g.H * g.W * p.ldx;
+  const T* xb0 = (const T*)p.x + (long)b * g.D * g.H * g.W * p.ldx;   // depth slice 0 of batch b
   const T* wpk = (const T*)p.wp;
   const int ntg = (Tn + p.tg - 1) / p.tg;
-  const int S = nq * ntg;   // pipeline stages: (channel chunk, tap group)
+  const int S = nqq * ntg;   // pipeline stages: (depth tap, channel chunk, tap group)
+  // chunk qq = (kdi, q): input depth slice din = dz*sd + kdi - pad_d (a slice outside the volume is zero padding)
+  auto slice_of = [&](int qq) { return dz * g.sd + qq / nq - g.pad_d; };
+  auto slice_ok = [&](int qq) { const int din = slice_of(qq); return din >= 0 && din < g.D; };
+  auto xb_of = [&](int qq) { return xb0 + (long)slice_of(qq) * g.H * g.W * p.ldx; };
 
   // Software pipeline: the global loads of stage s+1 (its tap-group weights and, at a chunk boundary, its halo tile)
   // are issued into registers BEFORE the MFMAs of stage s and committed to the other LDS buffer after them, so the
@@ -125,20 +130,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
     }
   }
 
-  auto halo_issue = [&](int q) {   // vector path only (host guarantees vec_in when pf_halo)
+  auto halo_issue = [&](int qq) {   // vector path only (host guarantees vec_in when pf_halo)
+    const int q = qq % nq;
+    const bool ok = slice_ok(qq);
+    const T* xb = xb_of(qq);
 #pragma unroll
     for (int j = 0; j < HPF; ++j) {
       rh[j] = u32x4{0u, 0u, 0u, 0u};
-      if (h_src[j] >= 0 && q * CK + h_ch[j] < p.Cin)
+      if (ok && h_src[j] >= 0 && q * CK + h_ch[j] < p.Cin)
         rh[j] = *reinterpret_cast<const u32x4*>(xb + h_src[j] + q * CK);
     }
   };
-  auto halo_commit = [&](int q, unsigned char* dst) {
+  auto halo_commit = [&](int qq, unsigned char* dst) {
+    const int q = qq % nq;
+    const bool ok = slice_ok(qq);
 #pragma unroll
     for (int j = 0; j < HPF; ++j) {
       if (h_lds[j] >= 0) {
         u32x4 raw = rh[j];
-        if (p.in_scale && h_src[j] >= 0) {
+        if (p.in_scale && ok && h_src[j] >= 0) {
           const int ch0 = q * CK + h_ch[j];
           if (ch0 < p.Cin) {   // zero padding (spatial or channel) stays zero
             float f[V];
@@ -157,17 +167,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
       }
     }
   };
-  auto halo_sync_stage = [&](int q, unsigned char* dst) {   // big halo tiles: plain staged copy (4 loads in flight)
+  auto halo_sync_stage = [&](int qq, unsigned char* dst) {   // big halo tiles: plain staged copy (4 loads in flight)
+    const int q = qq % nq;
     StageSrc ss;
-    ss.base = xb; ss.H = g.H; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin; ss.h0 = ih0; ss.w0 = iw0; ss.IH = IH; ss.IW = IW;
+    ss.base = xb_of(qq); ss.H = slice_ok(qq) ? g.H : 0; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin;
+    ss.h0 = ih0; ss.w0 = iw0; ss.IH = IH; ss.IW = IW;
     ss.scale = p.in_scale ? p.in_scale + grp * p.Cin : nullptr;
     ss.shift = p.in_scale ? p.in_shift + grp * p.Cin : nullptr;
     ss.relu = p.in_relu; ss.vec = p.vec_in; ss.magic_iw = magic_iw;
     stage_tile<T, 4>(dst, ss, q, sh, tid);
   };
-  auto w_issue = [&](int q, int t0) {
+  auto w_issue = [&](int qq, int t0) {   // packed weights are [kd][nq][T][Mpad][CK]: chunk index qq as is
     const int nt = min(p.tg, Tn - t0);
-    const T* base = wpk + ((long)(q * Tn + t0) * p.Mpad + n0) * CK;
+    const T* base = wpk + ((long)(qq * Tn + t0) * p.Mpad + n0) * CK;
 #pragma unroll
     for (int j = 0; j < WPF; ++j)
       if (w_tl[j] < nt) rw[j] = *reinterpret_cast<const u32x4*>(base + w_src[j]);
@@ -187,8 +199,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
     const int row = mi * 16 + l15;
     a_off[mi] = row * 128 + ((lg << 4) ^ (((row >> 1) & 7) << 4));
   }
-  auto compute = [&](int q, int t0, const unsigned char* halo, const unsigned char* wl) {
-    const int cq = min(CK, p.Cin - q * CK);
+  auto compute = [&](int qq, int t0, const unsigned char* halo, const unsigned char* wl) {
+    const int cq = min(CK, p.Cin - (qq % nq) * CK);
     const bool two = (cq + CK / 2 - 1) / (CK / 2) == 2;   // second 64-byte k-step present (wave-uniform)
     const int nt = min(p.tg, Tn - t0);
     int khi = t0 / g.kw, kwi = t0 - khi * g.kw;
@@ -234,17 +246,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
   };
 
   if (p.per_tap) {   // one stage per (chunk, tap): shifted tile + that tap's weights, no prefetch (rare, small layers)
-    for (int st = 0; st < nq * Tn; ++st) {
-      const int q = st / Tn, t = st - q * Tn;
+    for (int st = 0; st < nqq * Tn; ++st) {
+      const int q = st / Tn, t = st - q * Tn;   // q runs over (depth tap, channel chunk)
       const int khi = t / g.kw, kwi = t - khi * g.kw;
       __syncthreads();
       StageSrc ss;
-      ss.base = xb; ss.H = g.H; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin;
+      ss.base = xb_of(q); ss.H = slice_ok(q) ? g.H : 0; ss.W = g.W; ss.ld = p.ldx; ss.C = p.Cin;
       ss.h0 = ih0 + khi * d; ss.w0 = iw0 + kwi * d; ss.IH = IH; ss.IW = IW;
       ss.scale = p.in_scale ? p.in_scale + grp * p.Cin : nullptr;
       ss.shift = p.in_scale ? p.in_shift + grp * p.Cin : nullptr;
       ss.relu = p.in_relu; ss.vec = p.vec_in; ss.magic_iw = magic_iw;
-      stage_tile<T, 4>(halo0, ss, q, sh, tid);
+      stage_tile<T, 4>(halo0, ss, q % nq, sh, tid);
       w_issue(q, t);
       w_commit(q, t, wl0);
       __syncthreads();
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const FwdArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
 
-  T* yb = (T*)p.y + (long)b * g.Ho * g.Wo * p.ldy;
+  T* yb = (T*)p.y + (long)blockIdx.z * g.Ho * g.Wo * p.ldy;
 #pragma unroll
   for (int ni = 0; ni < NT_PIX; ++ni) {
     const int pt = wave * NT_PIX + ni;
@@ -378,7 +390,7 @@ int launch(const FwdArgs& a, size_t lds, hipStream_t s) {
     attr_set = 160 * 1024;
   }
   const ConvGeom& g = a.g;
-  dim3 grid(sdhip_cdiv(g.Ho, TH) * sdhip_cdiv(g.Wo, TW), sdhip_cdiv(a.Mpad, BN), g.B);
+  dim3 grid(sdhip_cdiv(g.Ho, TH) * sdhip_cdiv(g.Wo, TW), sdhip_cdiv(a.Mpad, BN), g.B * g.Do);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
@@ -408,6 +420,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                                 int B, int H, int W, int Cin, int ldx,
                                 int Ho, int Wo, int Cout, int ldy,
                                 int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                                int D, int Do, int kd, int sd, int pad_d,
                                 int in_relu, int groups, int act, int accumulate,
                                 int dtype, void* stream) {
   SDHIP_CHECK_ARG(x && wpacked && y, "conv2d_fwd: null pointer");
@@ -422,7 +435,8 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   const int es = conv_esize(dtype);
   FwdArgs a;
   a.x = x; a.wp = wpacked; a.y = y; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift; a.stats = stats;
-  a.g = ConvGeom{B, H, W, Ho, Wo, kh, kw, stride, dil, pad_t, pad_l};
+  SDHIP_CHECK_ARG(D >= 1 && Do >= 1 && kd >= 1 && sd >= 1 && (long)B * Do <= 65535, "conv2d_fwd: bad depth geometry");
+  a.g = ConvGeom{B, H, W, Ho, Wo, kh, kw, stride, dil, pad_t, pad_l, D, Do, kd, sd, pad_d};
   a.Cin = Cin; a.ldx = ldx; a.Cout = Cout; a.Mpad = (Cout + 15) & ~15; a.ldy = ldy;
   a.in_relu = in_relu; a.groups = groups; a.act = act; a.accumulate = accumulate;
   a.stats_ld = stats_ld > 0 ? stats_ld : Cout;
@@ -432,13 +446,13 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   a.vec_out = (ldy % 4 == 0) && (((uintptr_t)y % (4 * es)) == 0);
   int bn = a.Mpad > 64 ? 128 : (a.Mpad > 32 ? 64 : (a.Mpad > 16 ? 32 : 16));
   const int T = kh * kw;
-  const long blocks_big = (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) * B * sdhip_cdiv(a.Mpad, bn);
+  const long blocks_big = (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) * B * Do * sdhip_cdiv(a.Mpad, bn);
   bool big = blocks_big >= 512 && Wo >= 24;
   if (!big) {
     // small feature maps (DenseNet blocks 2-4, pooled pyramids): the launch cannot fill 256 CUs with pixel tiles alone,
     // so split the output channels over more workgroups (the input tile is re-read from L2, the serial
     // chunk-by-chunk latency chain per workgroup gets shorter and more of them overlap per CU).
-    const long px_blocks = (long)sdhip_cdiv(Ho, 4) * sdhip_cdiv(Wo, 16) * B;
+    const long px_blocks = (long)sdhip_cdiv(Ho, 4) * sdhip_cdiv(Wo, 16) * B * Do;
     while (bn > 32 && px_blocks * sdhip_cdiv(a.Mpad, bn) < 1024) bn >>= 1;
   }
   const int rows = a.Mpad < bn ? a.Mpad : bn;
@@ -447,7 +461,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   const int chunks_per_row = Cin <= CKh / 2 ? 4 : 8;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int th = big ? 8 : 4, tw = big ? 32 : 16;
-    const int per_tap = (kh > 1 || kw > 1) && dil >= 4;   // halo would be >= 4x the tile in each direction's holes
+    const int per_tap = (kh > 1 || kw > 1) && dil >= 4 && kd == 1;   // halo would be >= 4x the tile in each direction's holes
     const size_t halo = halo_bytes_of(a.g, th, tw, per_tap);
     const long halo_loads = (long)(halo / 128) * chunks_per_row;
     // register-prefetched (double-buffered) halo: small tiles, at most 4 loads per lane, vector loads only

@@ -74,10 +74,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgArgs p) {
   const int IH = (TH - 1) * s + (g.kh - 1) * d + 1, IW = (TW - 1) * s + (g.kw - 1) * d + 1;
   const int T_ = g.kh * g.kw;
   const unsigned magic_iw = div_magic(IW);
-  int by = blockIdx.y;                       // -> (output-channel block, channel chunk, tap group)
+  int by = blockIdx.y;                       // -> (output-channel block, depth tap, channel chunk, tap group)
   const int tgi = by % p.ntg; by /= p.ntg;
-  const int q = by % p.nq;
-  const int mb = by / p.nq;
+  const int q = by % p.nq; by /= p.nq;
+  const int kdi = by % g.kd;
+  const int mb = by / g.kd;
   const int t0 = tgi * p.tpb, nt = min(p.tpb, T_ - t0);
   const int m0 = mb * MB;
   const int ci_tile = wave % NTILE;
@@ -100,16 +101,19 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgArgs p) {
   float bsum = 0.f;  // bias gradient partial of channel (tid % CK), pixel stripe (tid / CK)
 
   const int tiles_w = (g.Wo + TW - 1) / TW, tiles_h = (g.Ho + TH - 1) / TH;
-  const int ntiles = g.B * tiles_h * tiles_w;
+  const int ntiles = g.B * g.Do * tiles_h * tiles_w;   // "images" = (batch, output depth slice)
   const bool wave_active = ci_tile * 16 < cin_q && co_tile0 * 16 < cout_m;  // wave-uniform
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int b = tile / (tiles_h * tiles_w);
-    const int tr = tile - b * tiles_h * tiles_w;
+    const int img = tile / (tiles_h * tiles_w);
+    const int tr = tile - img * tiles_h * tiles_w;
     const int oh0 = (tr / tiles_w) * TH, ow0 = (tr % tiles_w) * TW;
+    const int b = img / g.Do, dz = img - b * g.Do;
+    const int din = dz * g.sd + kdi - g.pad_d;       // input depth slice this depth tap reads
+    if (din < 0 || din >= g.D) continue;             // zero padding in depth: no contribution (uniform per workgroup)
     const int grp = p.groups > 1 ? b / (g.B / p.groups) : 0;
-    const T* xb = (const T*)p.x + (long)b * g.H * g.W * p.ldx;
-    const T* yb = (const T*)p.dy + (long)b * g.Ho * g.Wo * p.lddy;
+    const T* xb = (const T*)p.x + ((long)b * g.D + din) * g.H * g.W * p.ldx;
+    const T* yb = (const T*)p.dy + (long)img * g.Ho * g.Wo * p.lddy;
     __syncthreads();  // previous tile's fragments are consumed
     {   // X halo tile of channel chunk q (same LDS image as the forward kernel, fused prologue)
       StageSrc ss;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgArgs p) {
     }
     __syncthreads();
 
-    if (p.dbias && q == 0 && tgi == 0) {  // uniform: bias gradient = column sums of the dY tile
+    if (p.dbias && q == 0 && tgi == 0 && kdi == g.pad_d) {  // uniform: bias gradient = column sums of the dY tile (once)
       const int ch = tid % CK, stripe = tid / CK;
       if (ch < cout_m) {
         const int c = ch / V, e = ch % V;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgArgs p) {
     for (int tl = 0; tl < MAXTW; ++tl) {
       const int tt = tl * TAPL + tap_lane;
       if (tt < nt) {
-        float* dst = p.dwp + ((long)(q * T_ + t0 + tt) * p.Mpad) * CK;
+        float* dst = p.dwp + ((long)((kdi * p.nq + q) * T_ + t0 + tt) * p.Mpad) * CK;
 #pragma unroll
         for (int mi = 0; mi < NCO; ++mi) {
 #pragma unroll
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgArgs p) {
       }
     }
   }
-  if (p.dbias && q == 0 && tgi == 0) {
+  if (p.dbias && q == 0 && tgi == 0 && kdi == g.pad_d) {
     const int ch = tid % CK;
     if (ch < cout_m) atomicAdd(p.dbias + m0 + ch, bsum);
   }
@@ -227,8 +231,8 @@ int launch(const WgArgs& a, hipStream_t s) {
     attr_set = 1;
   }
   const int nmb = sdhip_cdiv(a.Cout, MB);
-  const int gy = nmb * a.nq * a.ntg;
-  const int ntiles = g.B * sdhip_cdiv(g.Ho, TH) * sdhip_cdiv(g.Wo, TW);
+  const int gy = nmb * g.kd * a.nq * a.ntg;
+  const int ntiles = g.B * g.Do * sdhip_cdiv(g.Ho, TH) * sdhip_cdiv(g.Wo, TW);
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;
   int gx = sdhip_cdiv(256 * per_cu, gy);
   if (gx > ntiles) gx = ntiles;
@@ -357,6 +361,7 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
                                   int B, int H, int W, int Cin, int ldx,
                                   int Ho, int Wo, int Cout, int lddy,
                                   int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                                  int D, int Do, int kd, int sd, int pad_d,
                                   int in_relu, int groups, int prezeroed, int dtype, void* stream) {
   SDHIP_CHECK_ARG(x && dy && dw_packed, "conv2d_wgrad: null pointer");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv2d_wgrad: unknown dtype %d", dtype);
@@ -367,7 +372,8 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
   const int V = dtype == SDHIP_BF16 ? 8 : 4, CK = 8 * V, T = kh * kw;
   WgArgs a;
   a.x = x; a.dy = dy; a.dwp = dw_packed; a.dbias = dbias; a.in_scale = in_scale; a.in_shift = in_shift;
-  a.g = ConvGeom{B, H, W, Ho, Wo, kh, kw, stride, dil, pad_t, pad_l};
+  SDHIP_CHECK_ARG(D >= 1 && Do >= 1 && kd >= 1 && sd >= 1, "conv2d_wgrad: bad depth geometry");
+  a.g = ConvGeom{B, H, W, Ho, Wo, kh, kw, stride, dil, pad_t, pad_l, D, Do, kd, sd, pad_d};
   a.Cin = Cin; a.ldx = ldx; a.Cout = Cout; a.Mpad = (Cout + 15) & ~15; a.lddy = lddy;
   a.in_relu = in_relu; a.groups = groups;
   a.nq = sdhip_cdiv(Cin, CK);
@@ -378,7 +384,7 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
   a.vec_x = (Cin % V == 0) && (ldx % V == 0) && (((uintptr_t)x & 15) == 0);
   a.vec_dy = (Cout % V == 0) && (lddy % V == 0) && (((uintptr_t)dy & 15) == 0);
   hipStream_t s = (hipStream_t)stream;
-  const long n = sdhip_conv_packed_elems(Cout, Cin, T, dtype);
+  const long n = (long)kd * sdhip_conv_packed_elems(Cout, Cin, T, dtype);
   if (!prezeroed) {
     if (hipMemsetAsync(dw_packed, 0, n * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
     if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");

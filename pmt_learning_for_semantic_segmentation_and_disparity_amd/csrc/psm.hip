@@ -1,0 +1,324 @@
+// PSMNet-specific pieces for gfx950 (models_psmnet/stackhourglass.py, submodule.py), all HBM bound:
+//
+//   * cost volume (stackhourglass.py:110-119): the reference zero-fills a (B,64,48,H/4,W/4) tensor and runs a
+//     48-iteration Python loop of strided slice copies; here one kernel writes the [B][D][H][W][2C] volume;
+//   * soft-argmin head (stackhourglass.py:138-155, submodule.py:56-64): trilinear x4 upsample -> softmax over the 192
+//     disparities -> sum_d p_d * d.  The reference materialises the (B,192,H,W) tensor four times per head; here one
+//     kernel evaluates the 192 interpolated costs of a pixel on the fly (online softmax), forward and backward;
+//   * zero insertion / strided gather: stride-s transposed convolutions (ConvTranspose3d of the hourglass,
+//     stackhourglass.py:25-29) and the data gradient of stride-s convolutions run as stride-1 convolutions over a
+//     zero-stuffed tensor.
+#include "sdhip_common.h"
+
+namespace {
+
+struct Vol { int N, D, H, W, C, ld; };   // [N][D][H][W] pixels of C channels, pixel stride ld
+
+inline dim3 grid_for(long items) {
+  long b = (items + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+template <typename T>
+bool vec_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+  const int n = Chunk<T>::N;
+  if (C % n) return false;
+  for (int l : lds) if (l % n) return false;
+  for (const void* p : ptrs) if (p && ((uintptr_t)p & 15)) return false;
+  return true;
+}
+
+// dense[n,d,h,w,:] <-> stuffed[n, d*sd, h*s, w*s, :]   (SCATTER: dense -> stuffed, stuffed pre-zeroed; else gather)
+template <typename T, bool VEC, bool SCATTER>
+__global__ __launch_bounds__(256) void stuff_kernel(const T* __restrict__ src, T* __restrict__ dst, Vol dense, Vol stuffed, int sd, int s) {
+  constexpr int N = Unit<T, VEC>::N;
+  const int units = dense.C / N;
+  const long npix = (long)dense.N * dense.D * dense.H * dense.W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix * units; i += (long)gridDim.x * 256) {
+    const long pix = i / units;
+    const int c0 = (int)(i - pix * units) * N;
+    const int w = (int)(pix % dense.W);
+    long r = pix / dense.W;
+    const int h = (int)(r % dense.H); r /= dense.H;
+    const int d = (int)(r % dense.D);
+    const long n = r / dense.D;
+    const long spix = ((n * stuffed.D + (long)d * sd) * stuffed.H + (long)h * s) * stuffed.W + (long)w * s;
+    float f[N];
+    if (SCATTER) {
+      Unit<T, VEC>::load(src + pix * dense.ld + c0, f);
+      Unit<T, VEC>::store(dst + spix * stuffed.ld + c0, f);
+    } else {
+      Unit<T, VEC>::load(src + spix * stuffed.ld + c0, f);
+      Unit<T, VEC>::store(dst + pix * dense.ld + c0, f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- cost volume
+// vol[b,i,h,w,0:C] = L[b,h,w,:], vol[b,i,h,w,C:2C] = R[b,h,w-i,:]   for w >= i, else 0
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void cost_volume_fwd(const T* __restrict__ L, const T* __restrict__ R, int ldl, T* __restrict__ vol,
+                                                       int B, int D, int H, int W, int C) {
+  constexpr int N = Unit<T, VEC>::N;
+  const int units = 2 * C / N;
+  const long nvox = (long)B * D * H * W;
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < nvox * units; it += (long)gridDim.x * 256) {
+    const long vox = it / units;
+    const int c0 = (int)(it - vox * units) * N;
+    const int w = (int)(vox % W);
+    long r = vox / W;
+    const int h = (int)(r % H); r /= H;
+    const int i = (int)(r % D);
+    const long b = r / D;
+    float f[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) f[e] = 0.f;
+    if (w >= i) {
+      if (c0 < C) Unit<T, VEC>::load(L + ((b * H + h) * W + w) * ldl + c0, f);
+      else Unit<T, VEC>::load(R + ((b * H + h) * W + (w - i)) * ldl + (c0 - C), f);
+    }
+    Unit<T, VEC>::store(vol + vox * (2 * C) + c0, f);
+  }
+}
+
+// gL[b,h,w,:] = sum_{i <= w} g[b,i,h,w,0:C];  gR[b,h,w,:] = sum_{i: w+i < W} g[b,i,h,w+i,C:2C]
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void cost_volume_bwd(const T* __restrict__ g, T* __restrict__ gL, T* __restrict__ gR, int ldl,
+                                                       int B, int D, int H, int W, int C) {
+  constexpr int N = Unit<T, VEC>::N;
+  const int units = C / N;
+  const long npix = (long)B * H * W;
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < npix * units; it += (long)gridDim.x * 256) {
+    const long pix = it / units;
+    const int c0 = (int)(it - pix * units) * N;
+    const int w = (int)(pix % W);
+    const long bh = pix / W;                // b*H + h
+    const long b = bh / H;
+    const int h = (int)(bh - b * H);
+    float aL[N], aR[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) { aL[e] = 0.f; aR[e] = 0.f; }
+    for (int i = 0; i < D; ++i) {
+      const long base = ((b * D + i) * H + h) * W;
+      float f[N];
+      if (i <= w) {
+        Unit<T, VEC>::load(g + (base + w) * (2 * C) + c0, f);
+#pragma unroll
+        for (int e = 0; e < N; ++e) aL[e] += f[e];
+      }
+      if (w + i < W) {
+        Unit<T, VEC>::load(g + (base + w + i) * (2 * C) + C + c0, f);
+#pragma unroll
+        for (int e = 0; e < N; ++e) aR[e] += f[e];
+      }
+    }
+    Unit<T, VEC>::store(gL + pix * ldl + c0, aL);
+    Unit<T, VEC>::store(gR + pix * ldl + c0, aR);
+  }
+}
+
+// ---------------------------------------------------------------- soft-argmin head
+struct Lin { int i0, i1; float l1; };
+__device__ __forceinline__ Lin lin_src(int d, float scale, int in) {   // ATen area_pixel source index, align_corners=False
+  float s = ((float)d + 0.5f) * scale - 0.5f;
+  if (s < 0.f) s = 0.f;
+  Lin r;
+  r.i0 = (int)s;
+  if (r.i0 > in - 1) r.i0 = in - 1;
+  r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+  r.l1 = fminf(fmaxf(s - (float)r.i0, 0.f), 1.f);
+  return r;
+}
+
+constexpr int kMaxD4 = 56;   // low-resolution disparity levels kept per lane in LDS (PSMNet: maxdisp/4 = 48)
+
+// pred[b,h,w] = sum_d softmax_d(trilinear(cost)[b,d,h,w]) * d ;  cost: [B][D4][H4][W4] (1 channel)
+template <typename T>
+__global__ __launch_bounds__(256) void softargmin_fwd(const T* __restrict__ cost, T* __restrict__ pred,
+                                                      int B, int D4, int H4, int W4, int Dout, int H, int W) {
+  __shared__ float cs[kMaxD4][256];
+  const float sd = (float)D4 / (float)Dout, shh = (float)H4 / (float)H, sw = (float)W4 / (float)W;
+  const long npix = (long)B * H * W;
+  for (long p0 = (long)blockIdx.x * 256; p0 < npix; p0 += (long)gridDim.x * 256) {
+    const long p = p0 + threadIdx.x;
+    const bool live = p < npix;
+    const int w = live ? (int)(p % W) : 0;
+    const int h = live ? (int)((p / W) % H) : 0;
+    const long b = live ? p / ((long)W * H) : 0;
+    const Lin lh = lin_src(h, shh, H4), lw = lin_src(w, sw, W4);
+    const float w00 = (1.f - lh.l1) * (1.f - lw.l1), w01 = (1.f - lh.l1) * lw.l1, w10 = lh.l1 * (1.f - lw.l1), w11 = lh.l1 * lw.l1;
+    for (int d4 = 0; d4 < D4; ++d4) {
+      const T* c = cost + ((b * D4 + d4) * H4) * (long)W4;
+      cs[d4][threadIdx.x] = w00 * Elem<T>::ld(c + lh.i0 * W4 + lw.i0) + w01 * Elem<T>::ld(c + lh.i0 * W4 + lw.i1) +
+                            w10 * Elem<T>::ld(c + lh.i1 * W4 + lw.i0) + w11 * Elem<T>::ld(c + lh.i1 * W4 + lw.i1);
+    }
+    float m = -INFINITY, s = 0.f, e = 0.f;
+    for (int d = 0; d < Dout; ++d) {
+      const Lin ld = lin_src(d, sd, D4);
+      const float v = (1.f - ld.l1) * cs[ld.i0][threadIdx.x] + ld.l1 * cs[ld.i1][threadIdx.x];
+      if (v > m) { const float k = __expf(m - v); s *= k; e *= k; m = v; }
+      const float x = __expf(v - m);
+      s += x; e = fmaf(x, (float)d, e);
+    }
+    if (live) Elem<T>::st(pred + p, e / s);
+  }
+}
+
+// gcost (f32, pre-zeroed, [B][D4][H4][W4]) += d pred / d cost * g
+template <typename T>
+__global__ __launch_bounds__(256) void softargmin_bwd(const T* __restrict__ cost, const T* __restrict__ g, float* __restrict__ gcost,
+                                                      int B, int D4, int H4, int W4, int Dout, int H, int W) {
+  __shared__ float cs[kMaxD4][256];   // interpolated low-res column per lane, then reused for its gradient
+  const float sd = (float)D4 / (float)Dout, shh = (float)H4 / (float)H, sw = (float)W4 / (float)W;
+  const long npix = (long)B * H * W;
+  for (long p0 = (long)blockIdx.x * 256; p0 < npix; p0 += (long)gridDim.x * 256) {
+    const long p = p0 + threadIdx.x;
+    const bool live = p < npix;
+    const int w = live ? (int)(p % W) : 0;
+    const int h = live ? (int)((p / W) % H) : 0;
+    const long b = live ? p / ((long)W * H) : 0;
+    const Lin lh = lin_src(h, shh, H4), lw = lin_src(w, sw, W4);
+    const float w00 = (1.f - lh.l1) * (1.f - lw.l1), w01 = (1.f - lh.l1) * lw.l1, w10 = lh.l1 * (1.f - lw.l1), w11 = lh.l1 * lw.l1;
+    for (int d4 = 0; d4 < D4; ++d4) {
+      const T* c = cost + ((b * D4 + d4) * H4) * (long)W4;
+      cs[d4][threadIdx.x] = w00 * Elem<T>::ld(c + lh.i0 * W4 + lw.i0) + w01 * Elem<T>::ld(c + lh.i0 * W4 + lw.i1) +
+                            w10 * Elem<T>::ld(c + lh.i1 * W4 + lw.i0) + w11 * Elem<T>::ld(c + lh.i1 * W4 + lw.i1);
+    }
+    float m = -INFINITY, s = 0.f, e = 0.f;
+    for (int d = 0; d < Dout; ++d) {
+      const Lin ld = lin_src(d, sd, D4);
+      const float v = (1.f - ld.l1) * cs[ld.i0][threadIdx.x] + ld.l1 * cs[ld.i1][threadIdx.x];
+      if (v > m) { const float k = __expf(m - v); s *= k; e *= k; m = v; }
+      const float x = __expf(v - m);
+      s += x; e = fmaf(x, (float)d, e);
+    }
+    const float predv = e / s, inv = 1.f / s;
+    const float gv = live ? Elem<T>::ld(g + p) : 0.f;
+    // d pred / d v_d = p_d (d - pred); fold the depth interpolation back onto the D4 levels.  Two passes over d keep the
+    // column values readable while their gradients are accumulated in registers of the SAME levels (i0 is monotone in d).
+    float acc0 = 0.f;      // gradient of level `cur`
+    float acc1 = 0.f;      // gradient of level `cur + 1`
+    int cur = 0;
+    for (int d = 0; d < Dout; ++d) {
+      const Lin ld = lin_src(d, sd, D4);
+      const float v = (1.f - ld.l1) * cs[ld.i0][threadIdx.x] + ld.l1 * cs[ld.i1][threadIdx.x];
+      const float dv = gv * __expf(v - m) * inv * ((float)d - predv);
+      while (cur < ld.i0) {   // level `cur` is complete: scatter it to the 4 low-resolution neighbours
+        if (live && acc0 != 0.f) {
+          float* gc = gcost + ((b * D4 + cur) * H4) * (long)W4;
+          atomicAdd(gc + lh.i0 * W4 + lw.i0, w00 * acc0); atomicAdd(gc + lh.i0 * W4 + lw.i1, w01 * acc0);
+          atomicAdd(gc + lh.i1 * W4 + lw.i0, w10 * acc0); atomicAdd(gc + lh.i1 * W4 + lw.i1, w11 * acc0);
+        }
+        acc0 = acc1; acc1 = 0.f; ++cur;
+      }
+      acc0 += (1.f - ld.l1) * dv;
+      if (ld.i1 != ld.i0) acc1 += ld.l1 * dv; else acc0 += ld.l1 * dv;
+    }
+    for (int k = 0; k < 2; ++k) {   // flush the last two levels
+      if (live && cur < D4 && acc0 != 0.f) {
+        float* gc = gcost + ((b * D4 + cur) * H4) * (long)W4;
+        atomicAdd(gc + lh.i0 * W4 + lw.i0, w00 * acc0); atomicAdd(gc + lh.i0 * W4 + lw.i1, w01 * acc0);
+        atomicAdd(gc + lh.i1 * W4 + lw.i0, w10 * acc0); atomicAdd(gc + lh.i1 * W4 + lw.i1, w11 * acc0);
+      }
+      acc0 = acc1; acc1 = 0.f; ++cur;
+    }
+  }
+}
+
+template <typename T>
+__global__ void f32_to_T_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) Elem<T>::st(dst + i, src[i]);
+}
+
+}  // namespace
+
+extern "C" int sdhip_stuff(const void* src, int lds_, void* dst, int ldd, int N, int D, int H, int W, int C,
+                           int sd, int s, int scatter, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(src && dst && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && sd >= 1 && s >= 1, "stuff: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "stuff: unknown dtype %d", dtype);
+  const int Ds = (D - 1) * sd + 1, Hs = (H - 1) * s + 1, Ws = (W - 1) * s + 1;
+  hipStream_t st = (hipStream_t)stream;
+  // scatter: src dense (ld lds_), dst stuffed (ld ldd, zeroed here);  gather: src stuffed (ld lds_), dst dense (ld ldd)
+  Vol dense{N, D, H, W, C, scatter ? lds_ : ldd}, stuffed{N, Ds, Hs, Ws, C, scatter ? ldd : lds_};
+  SDHIP_CHECK_ARG(dense.ld >= C && stuffed.ld >= C, "stuff: pixel stride smaller than channel count");
+  const long np = (long)N * D * H * W;
+  const int es = dtype == SDHIP_BF16 ? 2 : 4;
+  if (scatter) {
+    SDHIP_CHECK_ARG(ldd == C, "stuff: the zero-stuffed output must be dense");
+    if (hipMemsetAsync(dst, 0, (size_t)N * Ds * Hs * Ws * C * es, st) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "stuff: memset failed");
+  }
+#define GO(T, V) do { if (scatter) hipLaunchKernelGGL((stuff_kernel<T, V, true>), grid_for(np * (V ? C / Chunk<T>::N : C)), dim3(256), 0, st, (const T*)src, (T*)dst, dense, stuffed, sd, s); \
+                      else hipLaunchKernelGGL((stuff_kernel<T, V, false>), grid_for(np * (V ? C / Chunk<T>::N : C)), dim3(256), 0, st, (const T*)src, (T*)dst, dense, stuffed, sd, s); } while (0)
+  if (dtype == SDHIP_F32) { if (vec_ok<float>(C, {lds_, ldd}, {src, dst})) GO(float, true); else GO(float, false); }
+  else { if (vec_ok<bf16_t>(C, {lds_, ldd}, {src, dst})) GO(bf16_t, true); else GO(bf16_t, false); }
+#undef GO
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_cost_volume_fwd(const void* left, const void* right, int ld, void* vol, int B, int D, int H, int W, int C,
+                                     int dtype, void* stream) {
+  SDHIP_CHECK_ARG(left && right && vol && B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && ld >= C, "cost_volume_fwd: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "cost_volume_fwd: unknown dtype %d", dtype);
+  const long nv = (long)B * D * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SDHIP_F32) {
+    if (vec_ok<float>(C, {ld}, {left, right, vol})) hipLaunchKernelGGL((cost_volume_fwd<float, true>), grid_for(nv * (2 * C / 4)), dim3(256), 0, st, (const float*)left, (const float*)right, ld, (float*)vol, B, D, H, W, C);
+    else hipLaunchKernelGGL((cost_volume_fwd<float, false>), grid_for(nv * 2 * C), dim3(256), 0, st, (const float*)left, (const float*)right, ld, (float*)vol, B, D, H, W, C);
+  } else {
+    if (vec_ok<bf16_t>(C, {ld}, {left, right, vol})) hipLaunchKernelGGL((cost_volume_fwd<bf16_t, true>), grid_for(nv * (2 * C / 8)), dim3(256), 0, st, (const bf16_t*)left, (const bf16_t*)right, ld, (bf16_t*)vol, B, D, H, W, C);
+    else hipLaunchKernelGGL((cost_volume_fwd<bf16_t, false>), grid_for(nv * 2 * C), dim3(256), 0, st, (const bf16_t*)left, (const bf16_t*)right, ld, (bf16_t*)vol, B, D, H, W, C);
+  }
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_cost_volume_bwd(const void* gvol, void* gleft, void* gright, int ld, int B, int D, int H, int W, int C,
+                                     int dtype, void* stream) {
+  SDHIP_CHECK_ARG(gvol && gleft && gright && B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && ld >= C, "cost_volume_bwd: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "cost_volume_bwd: unknown dtype %d", dtype);
+  const long np = (long)B * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SDHIP_F32) {
+    if (vec_ok<float>(C, {ld}, {gvol, gleft, gright})) hipLaunchKernelGGL((cost_volume_bwd<float, true>), grid_for(np * (C / 4)), dim3(256), 0, st, (const float*)gvol, (float*)gleft, (float*)gright, ld, B, D, H, W, C);
+    else hipLaunchKernelGGL((cost_volume_bwd<float, false>), grid_for(np * C), dim3(256), 0, st, (const float*)gvol, (float*)gleft, (float*)gright, ld, B, D, H, W, C);
+  } else {
+    if (vec_ok<bf16_t>(C, {ld}, {gvol, gleft, gright})) hipLaunchKernelGGL((cost_volume_bwd<bf16_t, true>), grid_for(np * (C / 8)), dim3(256), 0, st, (const bf16_t*)gvol, (bf16_t*)gleft, (bf16_t*)gright, ld, B, D, H, W, C);
+    else hipLaunchKernelGGL((cost_volume_bwd<bf16_t, false>), grid_for(np * C), dim3(256), 0, st, (const bf16_t*)gvol, (bf16_t*)gleft, (bf16_t*)gright, ld, B, D, H, W, C);
+  }
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_softargmin_fwd(const void* cost, void* pred, int B, int D4, int H4, int W4, int Dout, int H, int W,
+                                    int dtype, void* stream) {
+  SDHIP_CHECK_ARG(cost && pred && B > 0 && D4 > 0 && D4 <= kMaxD4 && H4 > 0 && W4 > 0 && Dout > 0 && H > 0 && W > 0,
+                  "softargmin_fwd: bad arguments (at most %d low-resolution disparity levels)", kMaxD4);
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "softargmin_fwd: unknown dtype %d", dtype);
+  const long np = (long)B * H * W;
+  if (dtype == SDHIP_F32) hipLaunchKernelGGL(softargmin_fwd<float>, grid_for(np), dim3(256), 0, (hipStream_t)stream, (const float*)cost, (float*)pred, B, D4, H4, W4, Dout, H, W);
+  else hipLaunchKernelGGL(softargmin_fwd<bf16_t>, grid_for(np), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)cost, (bf16_t*)pred, B, D4, H4, W4, Dout, H, W);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_softargmin_bwd(const void* cost, const void* gpred, void* gcost, float* gcost_f32, int B, int D4, int H4, int W4,
+                                    int Dout, int H, int W, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(cost && gpred && gcost && gcost_f32 && B > 0 && D4 > 0 && D4 <= kMaxD4 && H4 > 0 && W4 > 0 && Dout > 0 && H > 0 && W > 0,
+                  "softargmin_bwd: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "softargmin_bwd: unknown dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const long nv = (long)B * D4 * H4 * W4, np = (long)B * H * W;
+  if (hipMemsetAsync(gcost_f32, 0, nv * sizeof(float), st) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "softargmin_bwd: memset failed");
+  if (dtype == SDHIP_F32) {
+    hipLaunchKernelGGL(softargmin_bwd<float>, grid_for(np), dim3(256), 0, st, (const float*)cost, (const float*)gpred, gcost_f32, B, D4, H4, W4, Dout, H, W);
+    hipLaunchKernelGGL(f32_to_T_kernel<float>, grid_for(nv), dim3(256), 0, st, gcost_f32, (float*)gcost, nv);
+  } else {
+    hipLaunchKernelGGL(softargmin_bwd<bf16_t>, grid_for(np), dim3(256), 0, st, (const bf16_t*)cost, (const bf16_t*)gpred, gcost_f32, B, D4, H4, W4, Dout, H, W);
+    hipLaunchKernelGGL(f32_to_T_kernel<bf16_t>, grid_for(nv), dim3(256), 0, st, gcost_f32, (bf16_t*)gcost, nv);
+  }
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}

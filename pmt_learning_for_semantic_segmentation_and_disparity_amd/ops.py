@@ -185,7 +185,8 @@ def _pack_params(kind, mode, Cout, Cin, T):
 def packed_weight(weight, kind, mode, dtype):
     """Pack an f32 parameter for the kernels (cached per parameter version, repacked after each optimizer step)."""
     Cout, Cin = (weight.shape[0], weight.shape[1]) if kind == 'conv' else (weight.shape[1], weight.shape[0])
-    T = weight.shape[2] * weight.shape[3]
+    kd = weight.shape[2] if weight.dim() == 5 else 1
+    T = weight.shape[-2] * weight.shape[-1]
     ent = _cache_entry(weight)
     key = (kind, mode, dtype)
     hit = ent.get(key)
@@ -195,15 +196,39 @@ def packed_weight(weight, kind, mode, dtype):
     ver = (weight._version, _pack_generation[0])
     if hit is not None and hit[0] == ver and not torch.cuda.is_current_stream_capturing():
         return hit[1]
-    M, K, sm, sk, flip = _pack_params(kind, mode, Cout, Cin, T)
     dt = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
-    buf = torch.empty(_lib.packed_elems(M, K, T, dt), dtype=dtype, device=weight.device)
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
-    call("sdhip_conv_pack_weights", ptr(w), ptr(buf), M, K, T, sm, sk, flip, dt, stream_ptr())
+    rows = _pack_rows(w, kind, mode, dt)
+    per = _lib.packed_elems(rows[0][2], rows[0][3], T, dt)
+    buf = torch.empty(per * kd, dtype=dtype, device=weight.device)
+    es = buf.element_size()
+    for src_off, dst_blk, M, K, T_, sm, sk, flip in rows:   # one launch per depth tap (3-D) / one in all (2-D)
+        call("sdhip_conv_pack_weights", ctypes_ptr(w.data_ptr() + 4 * src_off), ctypes_ptr(buf.data_ptr() + es * per * dst_blk),
+             M, K, T_, sm, sk, flip, dt, stream_ptr())
     ent[key] = (ver, buf)
     return buf
+
+
+def ctypes_ptr(addr):
+    import ctypes
+    return ctypes.c_void_p(addr)
+
+
+def _pack_rows(w, kind, mode, dt):
+    """[(src element offset, destination depth block, M, K, T, stride_m, stride_k, flip)] — one row per depth tap.
+    A 3-D weight (.., kd, kh, kw) is packed [kd][q][t][m][c]; with flip (data-grad / transposed orientation) the depth
+    taps are reversed as well as the in-plane taps."""
+    Cout, Cin = (w.shape[0], w.shape[1]) if kind == 'conv' else (w.shape[1], w.shape[0])
+    kd = w.shape[2] if w.dim() == 5 else 1
+    T = w.shape[-2] * w.shape[-1]
+    M, K, sm, sk, flip = _pack_params(kind, mode, Cout, Cin, T * kd)
+    # _pack_params' strides are in units of "taps per (m,k) pair" = kd*T for volumes; the tap index inside one depth tap is < T
+    rows = []
+    for kdi in range(kd):
+        rows.append((kdi * T, (kd - 1 - kdi) if flip else kdi, M, K, T, sm, sk, flip))
+    return rows
 
 
 def pack_descriptors(dtype):
@@ -216,28 +241,35 @@ def pack_descriptors(dtype):
         for (kind, mode, dt), (_, buf) in ent.items():
             if dt != dtype:
                 continue
-            Cout, Cin = (w.shape[0], w.shape[1]) if kind == 'conv' else (w.shape[1], w.shape[0])
-            T = w.shape[2] * w.shape[3]
-            M, K, sm, sk, flip = _pack_params(kind, mode, Cout, Cin, T)
-            rows.append([w.data_ptr(), buf.data_ptr(), M, K, T, sm, sk, flip])
+            dtc = _lib.BF16 if dt == torch.bfloat16 else _lib.F32
+            prow = _pack_rows(w, kind, mode, dtc)
+            per = _lib.packed_elems(prow[0][2], prow[0][3], prow[0][4], dtc)
+            for src_off, dst_blk, M, K, T, sm, sk, flip in prow:
+                rows.append([w.data_ptr() + 4 * src_off, buf.data_ptr() + buf.element_size() * per * dst_blk, M, K, T, sm, sk, flip])
     return rows
 
 
 class ConvSpec:
     """Geometry of one convolution in correlation form (what the kernels take)."""
-    __slots__ = ("kind", "kh", "kw", "stride", "dil", "pad_t", "pad_l", "Ho", "Wo")
+    __slots__ = ("kind", "kh", "kw", "stride", "dil", "pad_t", "pad_l", "Ho", "Wo", "D", "Do", "kd", "sd", "pad_d")
 
-    def __init__(self, kind, kh, kw, stride, dil, pad_t, pad_l, Ho, Wo):
+    def __init__(self, kind, kh, kw, stride, dil, pad_t, pad_l, Ho, Wo, D=1, Do=1, kd=1, sd=1, pad_d=0):
         self.kind, self.kh, self.kw, self.stride, self.dil = kind, kh, kw, stride, dil
         self.pad_t, self.pad_l, self.Ho, self.Wo = pad_t, pad_l, Ho, Wo
+        # depth axis of 3-D convolutions over [B][D][H][W][C] volumes (tensors of B*D "images"); 2-D: all ones / zero
+        self.D, self.Do, self.kd, self.sd, self.pad_d = D, Do, kd, sd, pad_d
+
+    def depth(self):
+        return (self.D, self.Do, self.kd, self.sd, self.pad_d)
 
 
 def _conv_launch(x, ldx, wp, y, ldy, bias, in_scale, in_shift, stats, B, H, W, Cin, Ho, Wo, Cout,
-                 kh, kw, stride, dil, pad_t, pad_l, in_relu, groups, act, accumulate, nrep=1):
-    """stats: None, or f64 [nrep][groups][2][>=Cout] (or a [groups][2][C] slice of a slab with nrep=1)."""
+                 kh, kw, stride, dil, pad_t, pad_l, in_relu, groups, act, accumulate, nrep=1, depth=(1, 1, 1, 1, 0)):
+    """stats: None, or f64 [nrep][groups][2][>=Cout] (or a [groups][2][C] slice of a slab with nrep=1).
+    B is the true batch; depth = (D, Do, kd, sd, pad_d) for volumes."""
     sld = stats.stride(-2) if stats is not None else 0
     call("sdhip_conv2d_fwd", ptr(x), ptr(wp), ptr(y), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(stats), sld, nrep,
-         B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, stride, dil, pad_t, pad_l,
+         B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, stride, dil, pad_t, pad_l, *depth,
          int(in_relu), groups, act, int(accumulate), dtype_code(x), stream_ptr())
 
 
@@ -319,23 +351,30 @@ def _bn_backward(gy, ldg, x, ldx, gx, ldgx, scale, shift, mean, invstd, gamma, n
 
 
 def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_relu, groups, need_x, need_w, bias=None):
+    has_bias = bias is not None
     """dgrad (w.r.t. the post-prologue input) and wgrad of one conv; returns (g_post, gw, gb)."""
     spec = ctx_spec
-    B, Cin, H, W = xv.shape
+    Bimg, Cin, H, W = xv.shape
+    B = Bimg // spec.D
     Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
     dt = dtype_code(xv)
-    T = spec.kh * spec.kw
     gpost = gw = gb = None
-    has_bias = bias is not None
     if need_x:
-        if spec.stride != 1:
-            raise _lib.SdhipError("data gradient of a strided convolution is not implemented (only image inputs feed one)")
         wd = packed_weight(weight, spec.kind, 'dgrad', xv.dtype)
-        gpost = empty_nhwc(B, Cin, H, W, xv.dtype, xv.device)
+        gpost = empty_nhwc(Bimg, Cin, H, W, xv.dtype, xv.device)
         pt = spec.dil * (spec.kh - 1) - spec.pad_t
         pl = spec.dil * (spec.kw - 1) - spec.pad_l
-        _conv_launch(g, ldg, wd, gpost, Cin, None, None, None, None, B, spec.Ho, spec.Wo, Cout, H, W, Cin,
-                     spec.kh, spec.kw, 1, spec.dil, pt, pl, False, 1, 0, False)
+        pd = (spec.kd - 1) - spec.pad_d
+        gsrc, ldsrc, Dg, Hg, Wg = g, ldg, spec.Do, spec.Ho, spec.Wo
+        if spec.stride != 1 or spec.sd != 1:
+            # strided convolution: its data gradient is a stride-1 correlation (flipped weights) over the zero-stuffed dY
+            Dg, Hg, Wg = (spec.Do - 1) * spec.sd + 1, (spec.Ho - 1) * spec.stride + 1, (spec.Wo - 1) * spec.stride + 1
+            gsrc = empty_nhwc(B * Dg, Cout, Hg, Wg, xv.dtype, xv.device)
+            call("sdhip_stuff", ptr(g), ldg, ptr(gsrc), Cout, B, spec.Do, spec.Ho, spec.Wo, Cout, spec.sd, spec.stride, 1, dt,
+                 stream_ptr())
+            ldsrc = Cout
+        _conv_launch(gsrc, ldsrc, wd, gpost, Cin, None, None, None, None, B, Hg, Wg, Cout, H, W, Cin,
+                     spec.kh, spec.kw, 1, spec.dil, pt, pl, False, 1, 0, False, 1, (Dg, spec.D, spec.kd, 1, pd))
     if need_w:
         gw, gb = wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu, groups)
     return gpost, gw, gb
@@ -356,11 +395,13 @@ def wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale=None, in_shift=None, in_
 
 
 def _wgrad_impl(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu, groups):
-    B, Cin, H, W = xv.shape
+    Bimg, Cin, H, W = xv.shape
+    B = Bimg // spec.D
     Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
     dt = dtype_code(xv)
     T = spec.kh * spec.kw
-    acc, pz = _zeros((_lib.packed_elems(Cout, Cin, T, dt),), torch.float32, xv.device)
+    per = _lib.packed_elems(Cout, Cin, T, dt)
+    acc, pz = _zeros((per * spec.kd,), torch.float32, xv.device)
     tw = _grad_target(weight)
     tb = _grad_target(bias) if bias is not None else None
     gb = None
@@ -380,15 +421,16 @@ def _wgrad_impl(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu
         pz = True
     call("sdhip_conv2d_wgrad", ptr(xv), ptr(g), ptr(acc), ptr(dbias), ptr(in_scale), ptr(in_shift),
          B, H, W, Cin, ldx, spec.Ho, spec.Wo, Cout, ldg, spec.kh, spec.kw, spec.stride, spec.dil,
-         spec.pad_t, spec.pad_l, int(in_relu), groups, int(pz), dt, stream_ptr())
-    # unpack by the WEIGHT's own channel count: the activation may carry zero-padded extra channels (8-channel images)
-    wCin = weight.shape[1] if spec.kind == 'conv' else weight.shape[0]
-    M, K, sm, sk, flip = _pack_params(spec.kind, 'fwd', Cout, wCin, T)
-    if tw is not None:
-        call("sdhip_conv_unpack_wgrad", ptr(acc), ptr(tw), M, K, T, sm, sk, flip, 1, dt, stream_ptr())
-        return None, gb
-    gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-    call("sdhip_conv_unpack_wgrad", ptr(acc), ptr(gw), M, K, T, sm, sk, flip, 0, dt, stream_ptr())
+         spec.pad_t, spec.pad_l, *spec.depth(), int(in_relu), groups, int(pz), dt, stream_ptr())
+    # unpack by the WEIGHT's own channel count (the activation may carry zero-padded extra channels: 8-channel images),
+    # depth tap by depth tap for 3-D weights
+    gw = None
+    target = tw
+    if target is None:
+        gw = target = torch.empty_like(weight, memory_format=torch.contiguous_format)
+    for src_off, blk, M, K, T_, sm, sk, flip in _pack_rows(weight, spec.kind, 'fwd', dt):
+        call("sdhip_conv_unpack_wgrad", ctypes_ptr(acc.data_ptr() + 4 * per * blk), ctypes_ptr(target.data_ptr() + 4 * src_off),
+             M, K, T_, sm, sk, flip, 1 if tw is not None else 0, dt, stream_ptr())
     return gw, gb
 
 
@@ -398,13 +440,15 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, spec, act):
         _require_gpu(x, weight)
-        B, Cin, H, W = x.shape
+        Bimg, Cin, H, W = x.shape
+        B = Bimg // spec.D
         xv, ldx = nhwc_view(x)
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
         wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
-        y = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
+        y = empty_nhwc(B * spec.Do, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
         _conv_launch(xv, ldx, wp, y, Cout, bias.detach() if bias is not None else None, None, None, None, B, H, W, Cin,
-                     spec.Ho, spec.Wo, Cout, spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, 1, act, False)
+                     spec.Ho, spec.Wo, Cout, spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, 1, act, False,
+                     1, spec.depth())
         ctx.spec, ctx.act, ctx.ldx = spec, act, ldx
         ctx.save_for_backward(xv, weight, bias, y if act else None)
         return y
@@ -413,7 +457,7 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         xv, weight, bias, ysaved = ctx.saved_tensors
         spec, act = ctx.spec, ctx.act
-        B = xv.shape[0]
+        B = xv.shape[0] // spec.D * spec.Do      # output images
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
         g, ldg = nhwc_view(gy)
         if act:   # activation fused in the epilogue: derivative from the stored output
@@ -434,15 +478,17 @@ class _ConvBNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, spec, bn, act, groups):
         _require_gpu(x, weight)
-        B, Cin, H, W = x.shape
+        Bimg, Cin, H, W = x.shape
+        Btrue = Bimg // spec.D
+        B = Btrue * spec.Do                      # output images
         xv, ldx = nhwc_view(x)
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
         wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
         yraw = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
         train = bn.training
         ws = _zeros((NREP, groups, 2, Cout), torch.float64, x.device)[0] if train else None
-        _conv_launch(xv, ldx, wp, yraw, Cout, None, None, None, ws, B, H, W, Cin, spec.Ho, spec.Wo, Cout,
-                     spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, groups, 0, False, NREP)
+        _conv_launch(xv, ldx, wp, yraw, Cout, None, None, None, ws, Btrue, H, W, Cin, spec.Ho, spec.Wo, Cout,
+                     spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, groups, 0, False, NREP, spec.depth())
         count = (B // groups) * spec.Ho * spec.Wo
         scale, shift, mean, invstd = _bn_finalize(ws, NREP, bn, count, groups)
         rv, ldr = nhwc_view(residual) if residual is not None else (None, 0)
@@ -458,7 +504,7 @@ class _ConvBNActFn(torch.autograd.Function):
     def backward(ctx, gy):
         xv, weight, gamma, beta, yraw, scale, shift, mean, invstd = ctx.saved_tensors
         spec, groups = ctx.spec, ctx.groups
-        B = xv.shape[0]
+        B = yraw.shape[0]
         Cout = yraw.shape[1]
         npix = B * spec.Ho * spec.Wo
         dt = dtype_code(xv)
@@ -926,3 +972,131 @@ def global_avg_pool(x):
     k = math.gcd(H, W)
     y = avgpool(x, k) if k > 1 else x
     return y.mean((2, 3), keepdim=True) if y.shape[2] * y.shape[3] > 1 else y
+
+
+# ============================================================================ 3-D convolutions and PSMNet ops
+def conv3d_spec(x, D, weight, stride=1, padding=1):
+    """nn.Conv3d(k, stride, padding) over a volume held as (B*D, C, H, W) NHWC images."""
+    Bimg, C, H, W = x.shape
+    kd, kh, kw = weight.shape[2:]
+    Do = (D + 2 * padding - kd) // stride + 1
+    Ho = (H + 2 * padding - kh) // stride + 1
+    Wo = (W + 2 * padding - kw) // stride + 1
+    return ConvSpec('conv', kh, kw, stride, 1, padding, padding, Ho, Wo, D, Do, kd, stride, padding)
+
+
+def conv3d_bn_act(x, D, weight, bn, stride=1, padding=1, act=0, residual=None, groups=1):
+    spec = conv3d_spec(x, D, weight, stride, padding)
+    return _ConvBNActFn.apply(x, weight, bn.weight, bn.bias, residual, spec, bn, act, groups), spec.Do
+
+
+def conv3d(x, D, weight, stride=1, padding=1):
+    spec = conv3d_spec(x, D, weight, stride, padding)
+    return _ConvFn.apply(x, weight, None, spec, 0), spec.Do
+
+
+class _StuffFn(torch.autograd.Function):
+    """Zero insertion: y[n, d*sd, h*s, w*s] = x[n,d,h,w] (extent (D-1)*sd+1 ...); backward is the strided gather."""
+
+    @staticmethod
+    def forward(ctx, x, D, sd, s):
+        _require_gpu(x)
+        Bimg, C, H, W = x.shape
+        B = Bimg // D
+        xv, ld = nhwc_view(x)
+        Ds, Hs, Ws = (D - 1) * sd + 1, (H - 1) * s + 1, (W - 1) * s + 1
+        y = empty_nhwc(B * Ds, C, Hs, Ws, x.dtype, x.device)
+        call("sdhip_stuff", ptr(xv), ld, ptr(y), C, B, D, H, W, C, sd, s, 1, dtype_code(x), stream_ptr())
+        ctx.cfg = (B, D, H, W, C, sd, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, D, H, W, C, sd, s = ctx.cfg
+        g, ld = nhwc_view(gy)
+        gx = empty_nhwc(B * D, C, H, W, gy.dtype, gy.device)
+        call("sdhip_stuff", ptr(g), ld, ptr(gx), C, B, D, H, W, C, sd, s, 0, dtype_code(gy), stream_ptr())
+        return gx, None, None, None
+
+
+def deconv3d_s2_bn_act(x, D, weight, bn, act=0, residual=None, groups=1):
+    """nn.ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1) + BatchNorm3d (models_psmnet/stackhourglass.py:25-29):
+    a stride-1 correlation with flipped taps over the zero-stuffed volume; output extent exactly 2x."""
+    Bimg, C, H, W = x.shape
+    xs = _StuffFn.apply(x, D, 2, 2)
+    Ds, Hs, Ws = 2 * D - 1, 2 * H - 1, 2 * W - 1
+    spec = ConvSpec('deconv', 3, 3, 1, 1, 1, 1, 2 * H, 2 * W, Ds, 2 * D, 3, 1, 1)
+    return _ConvBNActFn.apply(xs, weight, bn.weight, bn.bias, residual, spec, bn, act, groups), 2 * D
+
+
+class _CostVolumeFn(torch.autograd.Function):
+    """Concatenation cost volume of PSMNet (models_psmnet/stackhourglass.py:110-119) as (B*D, 2C, H, W) images."""
+
+    @staticmethod
+    def forward(ctx, left, right, D):
+        _require_gpu(left, right)
+        B, C, H, W = left.shape
+        lv, ldl = nhwc_view(left)
+        rv, ldr = nhwc_view(right)
+        if ldl != ldr:
+            lv = lv.contiguous(memory_format=torch.channels_last); rv = rv.contiguous(memory_format=torch.channels_last)
+            ldl = C
+        vol = empty_nhwc(B * D, 2 * C, H, W, left.dtype, left.device)
+        call("sdhip_cost_volume_fwd", ptr(lv), ptr(rv), ldl, ptr(vol), B, D, H, W, C, dtype_code(left), stream_ptr())
+        ctx.cfg = (B, C, H, W, D)
+        return vol
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W, D = ctx.cfg
+        gv, ld = nhwc_view(g)
+        if ld != 2 * C:
+            gv = gv.contiguous(memory_format=torch.channels_last)
+        gl = empty_nhwc(B, C, H, W, g.dtype, g.device)
+        gr = empty_nhwc(B, C, H, W, g.dtype, g.device)
+        call("sdhip_cost_volume_bwd", ptr(gv), ptr(gl), ptr(gr), C, B, D, H, W, C, dtype_code(g), stream_ptr())
+        return gl, gr, None
+
+
+def cost_volume(left, right, D):
+    return _CostVolumeFn.apply(left, right, D)
+
+
+class _SoftArgminFn(torch.autograd.Function):
+    """trilinear upsample -> softmax over disparity -> expectation (stackhourglass.py:138-155, submodule.py:56-64)."""
+
+    @staticmethod
+    def forward(ctx, cost, D4, maxdisp, H, W):
+        _require_gpu(cost)
+        Bimg, C, H4, W4 = cost.shape
+        if C != 1:
+            raise _lib.SdhipError("soft-argmin expects a 1-channel cost volume")
+        B = Bimg // D4
+        c = cost.contiguous()
+        pred = torch.empty((B, H, W), dtype=cost.dtype, device=cost.device)
+        call("sdhip_softargmin_fwd", ptr(c), ptr(pred), B, D4, H4, W4, maxdisp, H, W, dtype_code(cost), stream_ptr())
+        ctx.save_for_backward(c)
+        ctx.cfg = (B, D4, H4, W4, maxdisp, H, W)
+        return pred
+
+    @staticmethod
+    def backward(ctx, g):
+        (c,) = ctx.saved_tensors
+        B, D4, H4, W4, maxdisp, H, W = ctx.cfg
+        gc = torch.empty_like(c)
+        tmp = torch.empty(c.numel(), dtype=torch.float32, device=c.device)
+        call("sdhip_softargmin_bwd", ptr(c), ptr(g.contiguous()), ptr(gc), ptr(tmp), B, D4, H4, W4, maxdisp, H, W,
+             dtype_code(c), stream_ptr())
+        return gc, None, None, None, None
+
+
+def soft_argmin(cost, D4, maxdisp, H, W):
+    return _SoftArgminFn.apply(cost, D4, maxdisp, H, W)
+
+
+def relu(x):
+    return affine_act(x, None, None, None, 1)
+
+
+def add(x, y):
+    return affine_act(x, None, None, y, 0)

@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--model", default="minidsnetExt", choices=["minidsnetExt", "psmnet"],
+                    help="psmnet = BASELINE config 3 (PSMNet(192), build-defined loss: mean L1 of the three predictions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -39,10 +41,13 @@ def parse():
     return ap.parse_args()
 
 
-def build_model(dtype):
+def build_model(dtype, name="minidsnetExt"):
     from oracle.ref_models import CFG  # plain attribute bag (the argparse fields the model reads); no compute
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
     torch.manual_seed(0)
+    if name == "psmnet":
+        from pmt_learning_for_semantic_segmentation_and_disparity_amd.psmnet import PSMNet
+        return PSMNet(192).cuda().train()
     m = N.minidsnetExt(CFG(dropout=0.0, aspp=0, use_att=1), labels=2, pretrained=False, patch_type='1dcorr', backbone='densenet')
     return m.cuda().train()
 
@@ -121,8 +126,12 @@ def main():
         pg = dist.group.WORLD
     from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    model = build_model(dtype)
-    step = TrainStep(model, dtype=dtype, use_graph=not a.no_graph, world_size=world, process_group=pg)
+    model = build_model(dtype, a.model)
+    loss_fn = None
+    if a.model == "psmnet":
+        from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops as _ops
+        loss_fn = lambda outs, seg, disp: _ops.mean_l1_loss(outs, disp[:, 0])
+    step = TrainStep(model, dtype=dtype, use_graph=not a.no_graph, world_size=world, process_group=pg, loss_fn=loss_fn)
     batch = synthetic_batch(a.batch, a.height, a.width, seed=1234 + rank)
     for _ in range(a.warmup):
         loss = step(*batch)
@@ -148,15 +157,17 @@ def main():
                "unit": "stereo-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "minidsnetExt (densenet121, 1dcorr, aspp 0; the live PyTorch form of baseline_SDnet*) "
-                                      "train step fwd+loss(CE+CE+Lovasz+L1)+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s"
+               "config": {"workload": ("minidsnetExt (densenet121, 1dcorr, aspp 0; the live PyTorch form of baseline_SDnet*) "
+                                       "train step fwd+loss(CE+CE+Lovasz+L1)+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s"
+                                       if a.model == "minidsnetExt" else
+                                       "PSMNet(192) stacked hourglass train step fwd+loss(mean L1 x3)+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s")
                                       % (a.width, a.height, a.batch, "hipGraph" if not a.no_graph else "eager"),
                           "global_batch": a.batch * world, "parallelism": "dp%d" % world},
                "loss": round(lossv, 5)}
         sys.stderr.write("[bench] timed region done: %.3f ms/step\n" % (dt / a.steps * 1e3)); sys.stderr.flush()
         if not a.no_roofline:
             out["roofline"] = kernel_roofline(dtype, a.batch, a.height, a.width)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.model == "minidsnetExt":
             out["cpu_baseline"] = cpu_baseline(2, a.height, a.width, a.cpu_steps, a.cpu_threads)
         print(json.dumps(out))
     if world > 1:

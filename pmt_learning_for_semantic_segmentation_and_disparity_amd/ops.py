@@ -1100,3 +1100,30 @@ def relu(x):
 
 def add(x, y):
     return affine_act(x, None, None, y, 0)
+
+
+class _MeanL1Fn(torch.autograd.Function):
+    """mean over the predictions of mean |pred - target| — the (build-defined) PSMNet training loss: the reference has no
+    PSMNet training harness; value and gradients in one pass per prediction."""
+
+    @staticmethod
+    def forward(ctx, target, *preds):
+        _require_gpu(target, *preds)
+        loss = torch.zeros(1, dtype=torch.float64, device=target.device)
+        t = target.contiguous().float()
+        grads = []
+        for p in preds:
+            pv = p.contiguous()
+            g = torch.empty_like(pv)
+            call("sdhip_l1_loss", ptr(pv), ptr(t), ptr(g), ptr(loss), pv.numel(), 1.0 / len(preds), dtype_code(pv), stream_ptr())
+            grads.append(g)
+        ctx.save_for_backward(*grads)
+        return loss.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(ctx.saved_tensors)
+
+
+def mean_l1_loss(preds, target):
+    return _MeanL1Fn.apply(target, *preds)

@@ -31,8 +31,9 @@ def flatten_parameters(model):
 
 class TrainStep:
     def __init__(self, model, dtype=torch.bfloat16, lr=0.0015, betas=(0.9, 0.999), eps=1e-7, use_lovasz=True,
-                 use_graph=True, world_size=1, process_group=None, use_side_stream=True):
+                 use_graph=True, world_size=1, process_group=None, use_side_stream=True, loss_fn=None):
         self.model, self.dtype, self.use_lovasz = model, dtype, use_lovasz
+        self.loss_fn = loss_fn      # (outputs, seg, disp) -> scalar; default: the joint seg+disp loss of the reference step
         self.lr, self.betas, self.eps = lr, betas, eps
         self.world_size, self.pg = world_size, process_group
         parallel.configure(process_group, world_size)     # sync-BN statistics exchange + gradient all-reduce
@@ -76,7 +77,10 @@ class TrainStep:
         self.flat_g.zero_()
         self.pack_all()             # one launch packs every weight (forward and data-grad orientation)
         outs = self.model(left.to(self.dtype), right.to(self.dtype))
-        loss = ops.train_loss(outs[0], outs[1], outs[2], seg, disp, self.use_lovasz)
+        if self.loss_fn is not None:
+            loss = self.loss_fn(outs, seg, disp)
+        else:
+            loss = ops.train_loss(outs[0], outs[1], outs[2], seg, disp, self.use_lovasz)
         loss.backward()
         self.ctx.join()             # weight gradients ran on the side stream
         return loss.detach()

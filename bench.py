@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--model", default="minidsnetExt", choices=["minidsnetExt", "psmnet"],
+    ap.add_argument("--model", default="minidsnetExt", choices=["minidsnetExt", "psmnet", "dsnet"],
                     help="psmnet = BASELINE config 3 (PSMNet(192), build-defined loss: mean L1 of the three predictions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -45,6 +45,8 @@ def build_model(dtype, name="minidsnetExt"):
     from oracle.ref_models import CFG  # plain attribute bag (the argparse fields the model reads); no compute
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
     torch.manual_seed(0)
+    if name == "dsnet":
+        return N.dsnet(CFG(), labels=2, pretrained=False).cuda().train()
     if name == "psmnet":
         from pmt_learning_for_semantic_segmentation_and_disparity_amd.psmnet import PSMNet
         return PSMNet(192).cuda().train()
@@ -160,6 +162,8 @@ def main():
                "config": {"workload": ("minidsnetExt (densenet121, 1dcorr, aspp 0; the live PyTorch form of baseline_SDnet*) "
                                        "train step fwd+loss(CE+CE+Lovasz+L1)+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s"
                                        if a.model == "minidsnetExt" else
+                                       "dsnet (PyTorch port of baseline_SDnet_small_fixed, 2-D corr) train step fwd+loss+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s"
+                                       if a.model == "dsnet" else
                                        "PSMNet(192) stacked hourglass train step fwd+loss(mean L1 x3)+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s")
                                       % (a.width, a.height, a.batch, "hipGraph" if not a.no_graph else "eager"),
                           "global_batch": a.batch * world, "parallelism": "dp%d" % world},

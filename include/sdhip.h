@@ -247,6 +247,11 @@ int sdhip_softargmin_fwd(const void* cost, void* pred, int B, int D4, int H4, in
                          int dtype, void* stream);
 int sdhip_softargmin_bwd(const void* cost, const void* gpred, void* gcost, float* gcost_f32, int B, int D4, int H4, int W4,
                          int Dout, int H, int W, int dtype, void* stream);
+/* y = log_softmax(x) over the channel axis (F.log_softmax(.., dim=1), models/dsnet_t2.py:216,270) and its backward
+ * gx = gy - exp(y) * sum_c gy. */
+int sdhip_log_softmax_fwd(const void* x, int ldx, void* y, int ldy, long npix, int C, int dtype, void* stream);
+int sdhip_log_softmax_bwd(const void* gy, int ldg, const void* y, int ldy, void* gx, int ldgx, long npix, int C,
+                          int dtype, void* stream);
 
 #ifdef __cplusplus
 }

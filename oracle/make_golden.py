@@ -212,6 +212,36 @@ def gen_nets():
     save("nets", **arrays)
 
 
+def gen_dsnet():
+    from models import dsnet_t2 as D
+    arrays = {}
+    for mode in ("train", "eval"):
+        ref = fill_state_dict(D.dsnet(R.CFG(), labels=2, pretrained=False), 61)
+        ref.train() if mode == "train" else ref.eval()
+        a, b = rand_input(61, "left", (2, 3, 256, 256)), rand_input(61, "right", (2, 3, 256, 256))
+        seg = F.one_hot((rand_input(61, "seg", (2, 256, 256)) > 0.5).long(), 2).permute(0, 3, 1, 2).float()
+        disp = rand_input(61, "disp", (2, 1, 256, 256), 0.0, 8.0)
+        outs = ref(a, b)
+        # dsnet returns log-probabilities: NLL-style loss on them + L1 on both disparity heads
+        loss = torch.mean(torch.sum(-seg * outs[0], 1)) + torch.mean(torch.sum(-seg * outs[2], 1)) + F.l1_loss(outs[1], disp) + F.l1_loss(outs[3], disp)
+        loss.backward()
+        p = "dsnet.%s" % mode
+        for i, name in enumerate(("seg1", "disp", "seg2", "disp2")):
+            arrays.update(flat("%s.%s" % (p, name), sample(outs[i], 8)))
+        arrays["%s.loss" % p] = np.float64(loss.item())
+        for k, v in grad_norms(ref).items():
+            arrays["%s.gnorm.%s" % (p, k)] = v
+        mine = R.dsnet(R.CFG(), labels=2)
+        mine.load_state_dict(fill_state_dict(D.dsnet(R.CFG(), labels=2, pretrained=False), 61).state_dict() if mode == "train" else ref.state_dict())
+        mine.train() if mode == "train" else mine.eval()
+        for x, y in zip(mine(a, b), outs):
+            err = float((x - y).abs().max())
+            assert err < 2e-4 * max(1.0, float(y.abs().max())), (mode, err)
+        print("dsnet", mode, "oracle==reference, loss", loss.item())
+    arrays["meta.corr"] = np.array("assumed-semantics")
+    save("dsnet", **arrays)
+
+
 def gen_psmnet():
     import importlib
     SH = importlib.import_module("models_psmnet.stackhourglass")   # (the package re-exports the class under this name)
@@ -247,7 +277,7 @@ if __name__ == "__main__":
     _install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet"]
+    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet"]
     if "ops" in which:
         gen_ops()
     if "backbone" in which:
@@ -256,3 +286,5 @@ if __name__ == "__main__":
         gen_nets()
     if "psmnet" in which:
         gen_psmnet()
+    if "dsnet" in which:
+        gen_dsnet()

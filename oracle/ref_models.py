@@ -607,3 +607,85 @@ class PSMNet(nn.Module):
         if self.training:
             return self._regress(cost1, left.shape[2:]), self._regress(cost2, left.shape[2:]), pred3
         return pred3
+
+
+# --------------------------------------------------------------------------- dsnet (models/dsnet_t2.py:119-321)
+class dsnet(nn.Module):
+    """models/dsnet_t2.py:119-321 — the line-for-line PyTorch port of the TF baseline_SDnet_small_fixed graph
+    (2-D 17x17 correlation, stride-2 transposed convs in the segmentation decoder)."""
+
+    def __init__(self, CFG, labels=8, pretrained=False, backbone='densenet'):
+        super().__init__()
+        self.resnet_features = piramidNet(pretrained=pretrained)
+        for j in (1, 2, 3):
+            setattr(self, 'conv2d_ba%d' % j, _img_conv(3))
+        self.correlation_sampler = SpatialCorrelationSampler(1, (17, 17), 1, 0, dilation_patch=1)
+        self.corrConv2d = _c1x1(289, 128)
+        self.conv1d_1 = _c1x1(2048, 64)
+        self.Conv2DownUp1 = Conv2DownUp(64, 32, 3)
+        self.Conv2DownUp2 = nn.Sequential(Conv2DownUp(32, 32, 3, lastLayer=False), ConvTranspose2dSame(32, labels, 3, 1, padding='same', init_he=False))
+        self.Conv2DownUp3 = Conv2DownUp(32, 128, 3)
+        self.Conv2DownUp4 = Conv2DownUp(256, 64, 3)
+        self.conv1d_2 = _c1x1(65, 64)
+        self.Conv2DownUp5 = Conv2DownUp(64, 64, 5, lastLayer=False)
+        self.dispoutConv = ConvTranspose2dSame(64, 1, 5, padding='same', init_he=False)
+        self.conv1d_3 = _c1x1(96, 64)
+        self.Conv2DownUp6 = Conv2DownUp(64, 64, 5)
+        self.conv1d_4 = _c1x1(192, 64)
+        self.conv2DT_BA1 = nn.Sequential(deconvbn(64, 32, 3, 2, 'same', 1), nn.ReLU(inplace=True))
+        self.conv1d_5 = _c1x1(96, 32)
+        self.conv2DT_BA2 = nn.Sequential(deconvbn(32, 32, 3, 2, 'same', 1), nn.ReLU(inplace=True))
+        self.conv1d_6 = _c1x1(33, 32)
+        self.Conv2DownUp7 = Conv2DownUp(32, 32, 5, lastLayer=False)
+        self.branchConv = ConvTranspose2dSame(32, labels, 5, padding='same', init_he=False)
+        self.conv1d_9 = _c1x1(448, 128)
+        self.conv1d_7 = _c1x1(256, 128)
+        self.Conv2DownUp8 = Conv2DownUp(32, 64, 3)
+        self.Conv2DownUp9 = Conv2DownUp(256, 64, 3)
+        self.conv1d_8 = _c1x1(65, 64)
+        self.Conv2DownUp10 = nn.Sequential(Conv2DownUp(64, 64, 5, lastLayer=False), ConvTranspose2dSame(64, 1, 5, padding='same', init_he=False))
+
+    def forward(self, input_a, input_b):
+        a = self.resnet_features(input_a)   # a_0..a_4, pyramid(tap 2), pyramid(tap 0)
+        b = self.resnet_features(input_b)
+        size = input_a.shape[2:]
+        xl3, xl2, xl1 = self.conv2d_ba3(input_a), self.conv2d_ba1(input_a), self.conv2d_ba2(input_a)
+        x = F.interpolate(torch.cat((a[4], b[4]), 1), scale_factor=2, mode='nearest')
+        x = self.Conv2DownUp1(self.conv1d_1(x))
+        x1 = F.interpolate(x, scale_factor=2, mode='nearest')
+        seg1 = F.interpolate(self.Conv2DownUp2(x1), scale_factor=8, mode='nearest')
+        seg1 = F.log_softmax(F.interpolate(seg1, size=size, mode='bilinear'), 1)
+        y = self.correlation_sampler(a[5], b[5])
+        n, ph, pw, h, w = y.shape
+        y = self.corrConv2d(y.reshape(n, ph * pw, h, w) / a[5].size(1))
+        y1 = F.interpolate(self.Conv2DownUp3(x1), size=y.shape[2:], mode='bilinear')
+        y = self.Conv2DownUp4(torch.cat((y1, y), 1))
+        y2 = F.interpolate(y, scale_factor=8)
+        xl2 = F.interpolate(xl2, size=y2.shape[2:], mode='bilinear')
+        d = self.dispoutConv(self.Conv2DownUp5(self.conv1d_2(torch.cat((y2, xl2), 1))))
+        disp = F.interpolate(d, size=size, mode='bilinear')
+        x = F.interpolate(x, scale_factor=4)
+        y3 = F.interpolate(y, scale_factor=2)
+        x = F.interpolate(x, y3.shape[2:], mode='bilinear')
+        x = self.Conv2DownUp6(self.conv1d_3(torch.cat((x, y3), 1)))
+        x = F.interpolate(x, a[1].shape[2:], mode='bilinear')
+        x = self.conv2DT_BA1(self.conv1d_4(torch.cat((x, a[1]), 1)))
+        x3 = x
+        x = F.interpolate(x, a[0].shape[2:], mode='bilinear')
+        x = self.conv2DT_BA2(self.conv1d_5(torch.cat((x, a[0]), 1)))
+        xl1 = F.interpolate(xl1, x.shape[2:], mode='bilinear')
+        s2 = self.branchConv(self.Conv2DownUp7(self.conv1d_6(torch.cat((x, xl1), 1))))
+        s2 = F.interpolate(F.log_softmax(s2, 1), size, mode='bilinear')
+        seg2 = 0.9 * s2 + 0.1 * seg1
+        y4 = self.conv1d_9(torch.cat((a[6], b[6]), 1))
+        y = F.interpolate(y, scale_factor=4)
+        y = F.interpolate(y, y4.shape[2:], mode='bilinear')
+        y = torch.cat((y4, y), 1)
+        y5 = self.Conv2DownUp8(x3)
+        y = F.interpolate(y, y5.shape[2:], mode='bilinear')
+        y = self.Conv2DownUp9(torch.cat((y5, y), 1))
+        y = F.interpolate(y, scale_factor=2)
+        xl3 = F.interpolate(xl3, y.shape[2:], mode='bilinear')
+        d2 = self.Conv2DownUp10(self.conv1d_8(torch.cat((y, xl3), 1)))
+        d2 = F.interpolate(d2, size, mode='bilinear')
+        return seg1, disp, seg2, 0.8 * d2 + 0.2 * disp

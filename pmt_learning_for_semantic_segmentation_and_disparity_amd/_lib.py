@@ -65,6 +65,8 @@ SIGNATURES = {
     "sdhip_cost_volume_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_softargmin_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_softargmin_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_log_softmax_fwd": [_p, _i, _p, _i, _l, _i, _i, _p],
+    "sdhip_log_softmax_bwd": [_p, _i, _p, _i, _p, _i, _l, _i, _i, _p],
     "sdhip_l1_loss": [_p, _p, _p, _p, _l, _f, _i, _p],
     "sdhip_stats_fix": [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _i, _i, _p],
 }

@@ -173,3 +173,49 @@ extern "C" int sdhip_dropout(const void* x, void* y, const long* seed, long laye
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }
+
+// ---- log_softmax over the channel axis of an NHWC tensor (F.log_softmax(x, dim=1) of models/dsnet_t2.py:216,270)
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, long npix, int C) {
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+    const T* xp = x + p * ldx;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, Elem<T>::ld(xp + c));
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += __expf(Elem<T>::ld(xp + c) - mx);
+    const float lse = mx + __logf(se);
+    for (int c = 0; c < C; ++c) Elem<T>::st(y + p * ldy + c, Elem<T>::ld(xp + c) - lse);
+  }
+}
+// gx = gy - exp(y) * sum_c gy   (y = log_softmax output)
+template <typename T>
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const T* __restrict__ gy, int ldg, const T* __restrict__ y, int ldy,
+                                                              T* __restrict__ gx, int ldgx, long npix, int C) {
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += Elem<T>::ld(gy + p * ldg + c);
+    for (int c = 0; c < C; ++c)
+      Elem<T>::st(gx + p * ldgx + c, Elem<T>::ld(gy + p * ldg + c) - __expf(Elem<T>::ld(y + p * ldy + c)) * s);
+  }
+}
+}  // namespace
+
+extern "C" int sdhip_log_softmax_fwd(const void* x, int ldx, void* y, int ldy, long npix, int C, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(x && y && npix > 0 && C > 0 && ldx >= C && ldy >= C, "log_softmax_fwd: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "log_softmax_fwd: unknown dtype %d", dtype);
+  if (dtype == SDHIP_F32) hipLaunchKernelGGL(log_softmax_fwd_kernel<float>, grid_for(npix), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, npix, C);
+  else hipLaunchKernelGGL(log_softmax_fwd_kernel<bf16_t>, grid_for(npix), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, npix, C);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_log_softmax_bwd(const void* gy, int ldg, const void* y, int ldy, void* gx, int ldgx, long npix, int C,
+                                     int dtype, void* stream) {
+  SDHIP_CHECK_ARG(gy && y && gx && npix > 0 && C > 0 && ldg >= C && ldy >= C && ldgx >= C, "log_softmax_bwd: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "log_softmax_bwd: unknown dtype %d", dtype);
+  if (dtype == SDHIP_F32) hipLaunchKernelGGL(log_softmax_bwd_kernel<float>, grid_for(npix), dim3(256), 0, (hipStream_t)stream, (const float*)gy, ldg, (const float*)y, ldy, (float*)gx, ldgx, npix, C);
+  else hipLaunchKernelGGL(log_softmax_bwd_kernel<bf16_t>, grid_for(npix), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gy, ldg, (const bf16_t*)y, ldy, (bf16_t*)gx, ldgx, npix, C);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}

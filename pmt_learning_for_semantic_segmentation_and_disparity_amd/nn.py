@@ -82,15 +82,21 @@ class ConvTranspose2dSame(nn.Module):
 
     def _geom(self):
         c = self.ct2d
-        if self.padding != 'same' or c.stride[0] != 1:
-            raise NotImplementedError("ConvTranspose2dSame: only padding='same', stride=1 is on the native path")
+        if self.padding != 'same' or c.dilation[0] != 1 and c.stride[0] != 1:
+            raise NotImplementedError("ConvTranspose2dSame: only padding='same' is on the native path")
         return dict(kind='deconv', stride=1, dilation=c.dilation[0], padding='ctsame')
 
     def run(self, x, act=0):
-        return ops.conv2d(x, self.ct2d.weight, self.ct2d.bias, act=act, **self._geom())
+        c = self.ct2d
+        if c.stride[0] != 1:   # stride 2 (dsnet's conv2DT_BA*): stride-1 correlation over the zero-stuffed input
+            return ops.deconv2d_strided(x, c.weight, c.bias, c.stride[0], act=act)
+        return ops.conv2d(x, c.weight, c.bias, act=act, **self._geom())
 
     def run_bn(self, x, bn, act=0, residual=None, groups=1):
-        return ops.conv_bn_act(x, self.ct2d.weight, bn, act=act, residual=residual, groups=groups, **self._geom())
+        c = self.ct2d
+        if c.stride[0] != 1:
+            return ops.deconv2d_strided(x, c.weight, None, c.stride[0], bn=bn, act=act, residual=residual, groups=groups)
+        return ops.conv_bn_act(x, c.weight, bn, act=act, residual=residual, groups=groups, **self._geom())
 
     def forward(self, x):
         return self.run(x)
@@ -368,3 +374,115 @@ class minidsnetExt(nn.Module):
 
 def _const(v, n, device):
     return torch.full((1, n), v, dtype=torch.float32, device=device)
+
+
+class piramidNet(nn.Module):
+    """models/dsnet_t2.py:324-390 (the pyramid of `dsnet`): taps + pyramid over tap 2 + pyramid over tap 0."""
+
+    def __init__(self, pretrained=False):
+        super().__init__()
+        self.resnet_features = densenet121(pretrained)
+        pv = [128, 64, 32, 16, 8]
+        for j in range(5):
+            setattr(self, 'branch0_%d' % j, _pool_branch(pv[j], 64))
+        for j in range(3):
+            setattr(self, 'branch1_%d' % j, _pool_branch(pv[j + 2], 256))
+
+    def forward(self, x, groups=1):
+        o = self.resnet_features(x, groups)
+        b0 = _pyramid([getattr(self, 'branch0_%d' % j) for j in range(5)], o[0], groups)
+        b2 = _pyramid([getattr(self, 'branch1_%d' % j) for j in range(3)], o[2], groups)
+        return o[0], o[1], o[2], o[3], o[4], b2, b0
+
+
+class dsnet(nn.Module):
+    """models/dsnet_t2.py:119-321 — the PyTorch port of the TF `baseline_SDnet_small_fixed` graph (BASELINE config 2):
+    2-D 17x17 correlation, stride-2 transposed convs, log-softmax heads blended 0.9/0.1 and 0.8/0.2.
+    forward(left, right) -> (seg_branch, disp_out, seg_branch2, disp_out2)."""
+
+    def __init__(self, CFG, labels=8, pretrained=False, backbone='densenet'):
+        super().__init__()
+        self.resnet_features = piramidNet(pretrained=pretrained)
+        for j in (1, 2, 3):
+            setattr(self, 'conv2d_ba%d' % j, _img_conv(3))
+        self.correlation_sampler = SpatialCorrelationSampler(1, (17, 17), 1, 0, dilation_patch=1)
+        self.corrConv2d = _c1x1(289, 128)
+        self.conv1d_1 = _c1x1(2048, 64)
+        self.Conv2DownUp1 = Conv2DownUp(64, 32, 3)
+        self.Conv2DownUp2 = nn.Sequential(Conv2DownUp(32, 32, 3, lastLayer=False), ConvTranspose2dSame(32, labels, 3, 1, padding='same', init_he=False))
+        self.Conv2DownUp3 = Conv2DownUp(32, 128, 3)
+        self.Conv2DownUp4 = Conv2DownUp(256, 64, 3)
+        self.conv1d_2 = _c1x1(65, 64)
+        self.Conv2DownUp5 = Conv2DownUp(64, 64, 5, lastLayer=False)
+        self.dispoutConv = ConvTranspose2dSame(64, 1, 5, padding='same', init_he=False)
+        self.conv1d_3 = _c1x1(96, 64)
+        self.Conv2DownUp6 = Conv2DownUp(64, 64, 5)
+        self.conv1d_4 = _c1x1(192, 64)
+        self.conv2DT_BA1 = nn.Sequential(deconvbn(64, 32, 3, 2, 'same', 1), nn.ReLU(inplace=True))
+        self.conv1d_5 = _c1x1(96, 32)
+        self.conv2DT_BA2 = nn.Sequential(deconvbn(32, 32, 3, 2, 'same', 1), nn.ReLU(inplace=True))
+        self.conv1d_6 = _c1x1(33, 32)
+        self.Conv2DownUp7 = Conv2DownUp(32, 32, 5, lastLayer=False)
+        self.branchConv = ConvTranspose2dSame(32, labels, 5, padding='same', init_he=False)
+        self.conv1d_9 = _c1x1(448, 128)
+        self.conv1d_7 = _c1x1(256, 128)
+        self.Conv2DownUp8 = Conv2DownUp(32, 64, 3)
+        self.Conv2DownUp9 = Conv2DownUp(256, 64, 3)
+        self.conv1d_8 = _c1x1(65, 64)
+        self.Conv2DownUp10 = nn.Sequential(Conv2DownUp(64, 64, 5, lastLayer=False), ConvTranspose2dSame(64, 1, 5, padding='same', init_he=False))
+
+    def forward(self, input_a, input_b):
+        B, _, H, W = input_a.shape
+        both8 = torch.zeros((2 * B, H, W, 8), dtype=input_a.dtype, device=input_a.device)
+        both8[:B, :, :, :3] = input_a.permute(0, 2, 3, 1)
+        both8[B:, :, :, :3] = input_b.permute(0, 2, 3, 1)
+        both = both8.permute(0, 3, 1, 2)
+        img_a = both[:B]
+        t = self.resnet_features(both, groups=2)
+        a = [u[:B] for u in t]
+        b = [u[B:] for u in t]
+        size = (H, W)
+        up = ops.interpolate
+        xl3 = self.conv2d_ba3[0].fused(img_a, act=1)
+        xl2 = self.conv2d_ba1[0].fused(img_a, act=1)
+        xl1 = self.conv2d_ba2[0].fused(img_a, act=1)
+        x = up(ops.concat([a[4], b[4]]), scale_factor=2, mode='nearest')
+        x = self.Conv2DownUp1(self.conv1d_1[0].run(x, act=1))
+        x1 = up(x, scale_factor=2, mode='nearest')
+        seg1 = up(self.Conv2DownUp2[1](self.Conv2DownUp2[0](x1)), scale_factor=8, mode='nearest')
+        seg1 = ops.log_softmax(up(seg1, size=size, mode='bilinear'))
+        y = self.correlation_sampler(a[5], b[5])
+        n, ph, pw, h, w = y.shape
+        y = y.reshape(n, ph * pw, h, w)
+        y = self.corrConv2d[0].run(ops.affine_act(y, ops._const_vec(1.0 / a[5].size(1), ph * pw, y.device), None), act=1)
+        y1 = up(self.Conv2DownUp3(x1), size=y.shape[2:], mode='bilinear')
+        y = self.Conv2DownUp4(ops.concat([y1, y]))
+        y2 = up(y, scale_factor=8)
+        xl2 = up(xl2, size=y2.shape[2:], mode='bilinear')
+        d = self.dispoutConv(self.Conv2DownUp5(self.conv1d_2[0].run(ops.concat([y2, xl2]), act=1)))
+        disp = up(d, size=size, mode='bilinear')
+        x = up(x, scale_factor=4)
+        y3 = up(y, scale_factor=2)
+        x = up(x, size=y3.shape[2:], mode='bilinear')
+        x = self.Conv2DownUp6(self.conv1d_3[0].run(ops.concat([x, y3]), act=1))
+        x = up(x, size=a[1].shape[2:], mode='bilinear')
+        x = self.conv2DT_BA1[0].fused(self.conv1d_4[0].run(ops.concat([x, a[1]]), act=1), act=1)
+        x3 = x
+        x = up(x, size=a[0].shape[2:], mode='bilinear')
+        x = self.conv2DT_BA2[0].fused(self.conv1d_5[0].run(ops.concat([x, a[0]]), act=1), act=1)
+        xl1 = up(xl1, size=x.shape[2:], mode='bilinear')
+        s2 = self.branchConv(self.Conv2DownUp7(self.conv1d_6[0].run(ops.concat([x, xl1]), act=1)))
+        s2 = up(ops.log_softmax(s2), size=size, mode='bilinear')
+        seg2 = ops.axpby(0.9, s2, 0.1, seg1)
+        y4 = self.conv1d_9[0].run(ops.concat([a[6], b[6]]), act=1)
+        y = up(y, scale_factor=4)
+        y = up(y, size=y4.shape[2:], mode='bilinear')
+        y = ops.concat([y4, y])
+        y5 = self.Conv2DownUp8(x3)
+        y = up(y, size=y5.shape[2:], mode='bilinear')
+        y = self.Conv2DownUp9(ops.concat([y5, y]))
+        y = up(y, scale_factor=2)
+        xl3 = up(xl3, size=y.shape[2:], mode='bilinear')
+        d2 = self.Conv2DownUp10[1](self.Conv2DownUp10[0](self.conv1d_8[0].run(ops.concat([y, xl3]), act=1)))
+        d2 = up(d2, size=size, mode='bilinear')
+        return seg1, disp, seg2, ops.axpby(0.8, d2, 0.2, disp)

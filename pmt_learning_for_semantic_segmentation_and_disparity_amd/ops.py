@@ -1127,3 +1127,71 @@ class _MeanL1Fn(torch.autograd.Function):
 
 def mean_l1_loss(preds, target):
     return _MeanL1Fn.apply(target, *preds)
+
+
+# ============================================================================ dsnet extras
+class _LogSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        B, C, H, W = x.shape
+        xv, ld = nhwc_view(x)
+        y = empty_nhwc(B, C, H, W, x.dtype, x.device)
+        call("sdhip_log_softmax_fwd", ptr(xv), ld, ptr(y), C, B * H * W, C, dtype_code(x), stream_ptr())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        B, C, H, W = y.shape
+        g, ld = nhwc_view(gy)
+        gx = empty_nhwc(B, C, H, W, y.dtype, y.device)
+        call("sdhip_log_softmax_bwd", ptr(g), ld, ptr(y), C, ptr(gx), C, B * H * W, C, dtype_code(y), stream_ptr())
+        return gx
+
+
+def log_softmax(x):
+    return _LogSoftmaxFn.apply(x)
+
+
+_consts = {}
+
+
+def _const_vec(v, n, device):
+    key = (float(v), n, str(device))
+    if key not in _consts:
+        _consts[key] = torch.full((1, n), float(v), dtype=torch.float32, device=device)
+    return _consts[key]
+
+
+def axpby(a, x, b, y):
+    """a*x + b*y (the 0.9/0.1 and 0.8/0.2 head blends of models/dsnet_t2.py:272,308)."""
+    C = x.shape[1]
+    t = affine_act(y, _const_vec(b, C, x.device), None, None, 0)
+    return affine_act(x, _const_vec(a, C, x.device), None, t, 0)
+
+
+def deconv_same_strided_spec(x, weight, stride):
+    """ConvTranspose2dSame with stride > 1 (models/torch_model.py:320-346): full transposed conv of extent (H-1)*s+k,
+    cropped from start = full//2 - (s*H)//2 to s*H.  Run as a stride-1 correlation with flipped taps over the
+    zero-stuffed input: top/left padding (k-1) - start."""
+    B, C, H, W = x.shape
+    k = weight.shape[2]
+
+    def one(size):
+        full, target = (size - 1) * stride + k, size * stride
+        h, oh = full // 2, target // 2
+        start = h - (oh if h - oh >= 0 else h)
+        return (k - 1) - start, target
+    pt, Ho = one(H)
+    pl, Wo = one(W)
+    return ConvSpec('deconv', k, k, 1, 1, pt, pl, Ho, Wo)
+
+
+def deconv2d_strided(x, weight, bias, stride, bn=None, act=0, residual=None, groups=1):
+    xs = _StuffFn.apply(x, 1, 1, stride)
+    spec = deconv_same_strided_spec(x, weight, stride)
+    if bn is None:
+        return _ConvFn.apply(xs, weight, bias, spec, act)
+    return _ConvBNActFn.apply(xs, weight, bn.weight, bn.bias, residual, spec, bn, act, groups)

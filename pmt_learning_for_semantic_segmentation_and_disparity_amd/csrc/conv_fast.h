@@ -1,0 +1,513 @@
+// Fast path of the direct convolution (forward / data-gradient form) for gfx950.
+//
+// Same algorithm as conv_fwd.hip's general kernel (halo tile of one input-channel chunk staged once in LDS, all
+// kh*kw taps walk over it, tap-group weights double-buffered next to it), restricted to what the hot layers need —
+// 16-byte-aligned pixels (ld % 8 == 0 for bf16), no per-tap mode — so that the inner loop carries no per-element
+// conditions: every LDS fragment read is unconditional, the tap loop is a two-register-set software pipeline
+// (the reads of step u+1 are in flight behind the MFMAs of step u) and all tile geometry lives in SGPRs.
+//
+// LDS images (rows of RB = 64*KS bytes; KS = k-steps per row: 2 = 128-byte rows, 1 = 64-byte rows for Cin <= 32 bf16):
+//   halo  : row = ih * IWp + iw with the row pitch IWp rounded up to a multiple of 8, so that the swizzle key of a
+//           pixel does not depend on its tile row, on the tap's kernel row or on the 16-pixel column block
+//   weight: row = tap_in_group * BN + m
+// 16-byte chunk c of row r sits at chunk slot  c ^ (r & 6)        (KS = 2)
+//                                              c ^ ((r >> 1) & 2) (KS = 1)
+// which is conflict-free for ds_read_b128 under the gfx950 lane grouping {0-3,12-15,20-27},{4-11,16-19,28-31},...
+// for EVERY alignment of the 16 consecutive rows a fragment read touches (found by exhaustive search; the plain
+// (r >> 1) & 7 key is 2-way conflicted for half of the tap shifts).
+#pragma once
+#include "conv_common.h"
+
+namespace {
+
+struct FastArgs {
+  const void* x; const void* wp; void* y;
+  const float* bias; const float* in_scale; const float* in_shift; double* stats;
+  int B, H, W, Ho, Wo, kh, kw, stride, dil, pad_t, pad_l;
+  int D, Do, kd, sd, pad_d;
+  int Cin, ldx, Cout, Mpad, ldy;
+  int in_relu, bpg, act, accumulate;   // bpg: images per statistics group
+  int tg, stats_ld, nrep, tail, dma;   // tail: Cin % (elements per 16 bytes) != 0 -> mask the last chunk; dma: halo by LDS-DMA
+  long rep_stride;
+};
+
+// source of every padding / dead lane of an LDS-DMA load
+__device__ __attribute__((aligned(16))) unsigned int sdhip_zero16[4] = {0u, 0u, 0u, 0u};
+
+// one global_load_lds_dwordx4: the wave's 64 lanes fetch 16 bytes each from their own address and the hardware writes
+// them to lds_wave_base + lane*16 (no VGPR destination; completion is tracked by vmcnt)
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// sum over the 16 lanes of a DPP row (the 16 pixels of one MFMA output tile); every lane gets the total.
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: four v_add_f32_dpp, no LDS traffic.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  return dpp_add<0x140>(v);
+}
+
+template <int KS> struct LdsRow;
+template <> struct LdsRow<2> {
+  static __device__ __forceinline__ int off(int row, int c) { return row * 128 + ((c ^ (row & 6)) << 4); }
+};
+template <> struct LdsRow<1> {
+  static __device__ __forceinline__ int off(int row, int c) { return row * 64 + ((c ^ ((row >> 1) & 2)) << 4); }
+};
+
+template <typename T, int TH, int TW, int BN, int KS>
+__global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
+  constexpr int V = Chunk<T>::N;          // elements per 16 bytes
+  constexpr int CK = 8 * V;               // channels per packed weight row (always 128 bytes)
+  constexpr int CKS = 4 * KS * V;         // channels per staged LDS row
+  constexpr int RB = 64 * KS;             // LDS row bytes
+  constexpr int SH = KS + 1;              // log2(16-byte chunks per LDS row)
+  constexpr int CH = 4 * KS;
+  constexpr int TWT = TW / 16, NPT = TH * TWT, NT_PIX = NPT / 4, NT_CO = BN / 16;
+  constexpr bool PF = (TH * TW <= 64);    // small tiles: halo register-prefetched and double-buffered
+  constexpr int HPF = 5;                  // load rounds of the prefetched (small-tile) halo
+  static_assert(NPT % 4 == 0 && NT_PIX >= 1, "every wave needs at least one 16-pixel MFMA tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int s = p.stride, d = p.dil;
+  const int tiles_w = (p.Wo + TW - 1) / TW;
+  const int ty = blockIdx.x / tiles_w;
+  const int oh0 = ty * TH, ow0 = (blockIdx.x - ty * tiles_w) * TW;
+  const int n0 = blockIdx.y * BN;
+  const int b = blockIdx.z / p.Do, dz = blockIdx.z - b * p.Do;
+  const int grp = b / p.bpg;
+  const int IH = (TH - 1) * s + (p.kh - 1) * d + 1, IW = (TW - 1) * s + (p.kw - 1) * d + 1;
+  const int IWp = (IW + 7) & ~7;
+  const int ih0 = oh0 * s - p.pad_t, iw0 = ow0 * s - p.pad_l;
+  const int Tn = p.kh * p.kw;
+  const int nq = KS == 2 ? (p.Cin + CK - 1) / CK : 1;
+  const int nqq = p.kd * nq;
+  const int halo_bytes = ((IH * IWp + (256 >> SH) - 1) & ~((256 >> SH) - 1)) * RB;   // whole load rounds (4 KiB)
+  const int wbuf_bytes = ((p.tg * BN + (256 >> SH) - 1) & ~((256 >> SH) - 1)) * RB;
+  unsigned char* const halo0 = smem;
+  unsigned char* const wl0 = smem + halo_bytes * (PF ? 2 : 1);
+
+  f32x4 acc[NT_CO][NT_PIX];
+#pragma unroll
+  for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT_PIX; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const T* const xb0 = (const T*)p.x + (long)b * p.D * p.H * p.W * p.ldx;
+  const T* const wpk = (const T*)p.wp;
+  const int ntg = (Tn + p.tg - 1) / p.tg;
+
+  // ---- fragment addressing: everything per lane is computed once ----
+  // wave's pixel tiles: pt = wave*NT_PIX + ni -> tile row pt / TWT, column block pt % TWT.  Row pitch IWp and the
+  // 16-pixel column step are multiples of 8 rows, so all of a lane's pixel tiles share one swizzle key per tap.
+  const int pt0 = wave * NT_PIX;
+  const int prow0 = ((pt0 / TWT) * s) * IWp + ((pt0 % TWT) * 16 + l15) * s;   // halo row of pixel tile 0, tap (0,0)
+  int pdelta[NT_PIX];   // wave-uniform row distance of pixel tile ni from pixel tile 0 (multiple of 8)
+#pragma unroll
+  for (int ni = 0; ni < NT_PIX; ++ni) {
+    const int pt = pt0 + ni;
+    pdelta[ni] = (((pt / TWT) - (pt0 / TWT)) * s * IWp + ((pt % TWT) - (pt0 % TWT)) * 16 * s) * RB;
+  }
+  const int lg4 = lg << 4;
+  const int a_base = LdsRow<KS>::off(l15, lg);   // weight row l15 (+ mi*16 rows, + tap*BN rows: key unchanged)
+
+  // ---- staging ----
+  // Lane <-> LDS mapping is LINEAR: in load round j lane tid fills bytes [(j*256 + tid)*16, +16) of the image, i.e.
+  // physical chunk slot (tid & (CH-1)) of row j*RPR + (tid >> SH).  The swizzle lives on the SOURCE side: the lane
+  // fetches logical chunk slot ^ key(row); RPR is a multiple of 8 rows, so the key (and the lane's channel offset)
+  // is the same in every round.  That is the layout `global_load_lds` (LDS-DMA, 1 KiB per wave-instruction, no
+  // VGPR round trip) writes, and the register path (BatchNorm prologue / odd channel tails) uses it too.
+  constexpr int RPR = 256 >> SH;            // LDS rows per round
+  const int rsub = tid >> SH;
+  const int c_l = (tid & (CH - 1)) ^ (KS == 2 ? (rsub & 6) : ((rsub >> 1) & 2));   // logical chunk this lane fetches
+  const int tid16 = tid * 16;
+  const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
+  const unsigned magic_iwp = div_magic(IWp);
+  const bool dma = p.dma;
+  const int h_rows = IH * IWp;
+  const int h_rounds = (h_rows + RPR - 1) / RPR;
+  int h_src[HPF];     // small tiles: element offset of the lane's chunk inside one depth slice per round, or -1 (padding)
+  if constexpr (PF) {
+#pragma unroll
+    for (int j = 0; j < HPF; ++j) {
+      const int row = rsub + j * RPR;
+      const int ih = fast_div(row, IWp, magic_iwp), iw = row - ih * IWp;
+      const int gh = ih0 + ih, gw = iw0 + iw;
+      h_src[j] = (row < h_rows && iw < IW && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) ? (gh * p.W + gw) * p.ldx + c_l * V : -1;
+    }
+  }
+  const int mvalid = min(BN, p.Mpad - n0);
+  const int w_rounds = (p.tg * BN + RPR - 1) / RPR;
+
+  u32x4 rh[HPF];
+  auto slice_of = [&](int qq) { return dz * p.sd + qq / nq - p.pad_d; };
+
+  auto mask_tail = [&](u32x4 raw, int ch0) -> u32x4 {   // zero the elements at channel >= Cin (rare: odd channel counts)
+    const int nv = p.Cin - ch0;
+    if (nv < V) {
+      float f[V];
+      Chunk<T>::unpack(raw, f);
+#pragma unroll
+      for (int e = 0; e < V; ++e) f[e] = e < nv ? f[e] : 0.f;
+      raw = Chunk<T>::pack(f);
+    }
+    return raw;
+  };
+  auto prologue = [&](u32x4 raw, int ch0) -> u32x4 {     // BatchNorm affine (+ReLU) of the producer, fused on load
+    float f[V];
+    Chunk<T>::unpack(raw, f);
+    const float* sc = p.in_scale + grp * p.Cin + ch0;
+    const float* sf = p.in_shift + grp * p.Cin + ch0;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      if (ch0 + e < p.Cin) {
+        const float v = fmaf(f[e], sc[e], sf[e]);
+        f[e] = p.in_relu ? fmaxf(v, 0.f) : v;
+      }
+    }
+    return Chunk<T>::pack(f);
+  };
+
+  // small tiles: issue the whole halo tile of chunk qq (DMA: straight into `dst`; register path: into rh[])
+  auto halo_issue = [&](int qq, unsigned char* dst) {
+    const int q = qq % nq;
+    const int din = slice_of(qq);
+    const bool ok = din >= 0 && din < p.D && q * CKS + c_l * V < p.Cin;
+    const T* xb = xb0 + (long)din * p.H * p.W * p.ldx + q * CKS;
+#pragma unroll
+    for (int j = 0; j < HPF; ++j) {
+      if (j < h_rounds) {
+        const T* src = (ok && h_src[j] >= 0) ? xb + h_src[j] : (const T*)sdhip_zero16;
+        if (dma) glds16(src, dst + j * 4096 + wave_lds);
+        else rh[j] = *reinterpret_cast<const u32x4*>(src);
+      }
+    }
+  };
+  auto halo_commit = [&](int qq, unsigned char* dst) {   // register path only
+    const int ch0 = (qq % nq) * CKS + c_l * V;
+    const int din = slice_of(qq);
+    const bool ok = din >= 0 && din < p.D && ch0 < p.Cin;
+#pragma unroll
+    for (int j = 0; j < HPF; ++j) {
+      if (j < h_rounds) {
+        u32x4 raw = rh[j];
+        if (ok && h_src[j] >= 0) {
+          if (p.tail) raw = mask_tail(raw, ch0);
+          if (p.in_scale) raw = prologue(raw, ch0);
+        }
+        *reinterpret_cast<u32x4*>(dst + j * 4096 + tid16) = raw;
+      }
+    }
+  };
+  // large tiles: stage the whole halo tile now (DMA: every round in flight at once; register path: 4 rounds at a time)
+  auto halo_sync_stage = [&](int qq, unsigned char* dst) {
+    const int ch0 = (qq % nq) * CKS + c_l * V;
+    const int din = slice_of(qq);
+    const bool ok = din >= 0 && din < p.D && ch0 < p.Cin;
+    const T* xb = xb0 + (long)din * p.H * p.W * p.ldx + ch0;
+    auto src_of = [&](int j) -> const T* {
+      const int row = rsub + j * RPR;
+      const int ih = fast_div(row, IWp, magic_iwp), iw = row - ih * IWp;
+      const int gh = ih0 + ih, gw = iw0 + iw;
+      const bool in = ok && iw < IW && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+      return in ? xb + (gh * p.W + gw) * p.ldx : (const T*)sdhip_zero16;
+    };
+    if (dma) {
+      for (int j = 0; j < h_rounds; ++j) glds16(src_of(j), dst + j * 4096 + wave_lds);
+    } else {
+      for (int j0 = 0; j0 < h_rounds; j0 += 4) {
+        u32x4 raw[4];
+        bool in[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const T* src = src_of(min(j0 + j, h_rounds - 1));
+          in[j] = src != (const T*)sdhip_zero16;
+          raw[j] = *reinterpret_cast<const u32x4*>(src);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j0 + j < h_rounds) {
+            if (in[j] && p.tail) raw[j] = mask_tail(raw[j], ch0);
+            if (in[j] && p.in_scale) raw[j] = prologue(raw[j], ch0);
+            *reinterpret_cast<u32x4*>(dst + (j0 + j) * 4096 + tid16) = raw[j];
+          }
+        }
+      }
+    }
+  };
+  // weights of stage (chunk qq, taps t0..): always LDS-DMA, issued right after the barrier that retired the buffer.
+  // Rows of output channels past Mpad (last block) and taps past the kernel are never used by a stored result: they
+  // re-read row 0 of the stage instead of being zero-filled.
+  auto w_issue = [&](int qq, int t0, unsigned char* dst) {   // packed weights are [kd][nq][T][Mpad][CK]
+    const int nt = min(p.tg, Tn - t0);
+    const T* base = wpk + ((long)(qq * Tn + t0) * p.Mpad + n0) * CK + c_l * V;
+    for (int j = 0; j < w_rounds; ++j) {
+      const int row = rsub + j * RPR;
+      const int tl = row / BN, m = row - tl * BN;   // BN is a power of two
+      const int off = (tl < nt && m < mvalid) ? (tl * p.Mpad + m) * CK : 0;
+      glds16(base + off, dst + j * 4096 + wave_lds);
+    }
+  };
+
+  // ---- the MFMA steps of one stage: (tap, k-step) pairs, two fragment register sets ----
+  auto compute = [&](int t0, const unsigned char* halo, const unsigned char* wl) {
+    const int nt = min(p.tg, Tn - t0);
+    const int n = nt * KS;
+    int khi = t0 / p.kw, kwi = t0 - khi * p.kw;
+    u32x4 af[2][NT_CO], bf[2][NT_PIX];
+    int b_addr = 0, a_addr = 0;
+    auto next_tap = [&](int tl) {   // fragment byte addresses of tap tl of the group, k-step 0, pixel tile 0 / cout tile 0
+      const int row = prow0 + (khi * d) * IWp + kwi * d;
+      if constexpr (KS == 2) b_addr = row * RB + (lg4 ^ ((row & 6) << 4));
+      else b_addr = row * RB + (lg4 ^ (((row >> 1) & 2) << 4));
+      a_addr = a_base + tl * (BN * RB);
+      if (++kwi == p.kw) { kwi = 0; ++khi; }
+    };
+    auto load = [&](int set, int ks) {
+      const unsigned char* ab = wl + (a_addr ^ (ks << 6));
+      const unsigned char* bb = halo + (b_addr ^ (ks << 6));
+#pragma unroll
+      for (int mi = 0; mi < NT_CO; ++mi) af[set][mi] = *reinterpret_cast<const u32x4*>(ab + mi * (16 * RB));
+#pragma unroll
+      for (int ni = 0; ni < NT_PIX; ++ni) bf[set][ni] = *reinterpret_cast<const u32x4*>(bb + pdelta[ni]);
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+      for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT_PIX; ++ni) Mma<T>::run(acc[mi][ni], af[set][mi], bf[set][ni]);
+    };
+    if constexpr (KS == 2) {
+      next_tap(0);
+      load(0, 0);
+      for (int tl = 0; tl < nt; ++tl) {
+        load(1, 1);
+        mma(0);
+        if (tl + 1 < nt) { next_tap(tl + 1); load(0, 0); }
+        mma(1);
+      }
+    } else {
+      next_tap(0);
+      load(0, 0);
+      for (int u = 0; u < n; u += 2) {
+        if (u + 1 < n) { next_tap(u + 1); load(1, 0); }
+        mma(0);
+        if (u + 2 < n) { next_tap(u + 2); load(0, 0); }
+        if (u + 1 < n) mma(1);
+      }
+    }
+  };
+
+  // ---- pipeline over stages (depth tap, channel chunk, tap group) ----
+  // The loads of stage st+1 (its tap-group weights and, at a chunk boundary of a small tile, its halo tile) are issued
+  // right after the barrier of stage st and land (DMA) or wait in registers behind the MFMAs of stage st.
+  if constexpr (PF) halo_issue(0, halo0); else halo_sync_stage(0, halo0);
+  w_issue(0, 0, wl0);
+  int q = 0, tgi = 0;
+  const int S = nqq * ntg;
+  for (int st = 0; st < S; ++st) {
+    const int t0 = tgi * p.tg;
+    unsigned char* halo = halo0 + ((PF && (q & 1)) ? halo_bytes : 0);
+    unsigned char* wl = wl0 + (st & 1) * wbuf_bytes;
+    if (PF && !dma && tgi == 0) halo_commit(q, halo);
+    // hipcc does not reliably drain LDS-DMA before a barrier reached over the loop back edge: wait explicitly
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                      // stage st is visible (DMA drained); every wave has finished stage st-1
+    int qn = q, tgn = tgi + 1;
+    if (tgn == ntg) { tgn = 0; ++qn; }
+    const bool more = st + 1 < S;
+    if (more) {
+      if (PF && tgn == 0) halo_issue(qn, halo0 + ((qn & 1) ? halo_bytes : 0));
+      w_issue(qn, tgn * p.tg, wl0 + ((st + 1) & 1) * wbuf_bytes);
+    }
+    compute(t0, halo, wl);
+    if (!PF && more && tgn == 0) {        // chunk boundary with a single (large) halo buffer
+      __syncthreads();
+      halo_sync_stage(qn, halo0);
+    }
+    q = qn; tgi = tgn;
+  }
+
+  // ---- epilogue: bias / activation / accumulate / store / BN statistics ----
+  // Everything wave-uniform (bias? activation? interior tile?) is decided once, outside the per-tile code, so the
+  // common case — interior tile, plain store — is straight-line: 4 VALU + one 8/16-byte store per 16x16 output tile.
+  if (p.bias) {
+#pragma unroll
+    for (int mi = 0; mi < NT_CO; ++mi) {
+      float bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = n0 + mi * 16 + 4 * lg + r;
+        bv[r] = co < p.Cout ? p.bias[co] : 0.f;
+      }
+#pragma unroll
+      for (int ni = 0; ni < NT_PIX; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][ni][r] += bv[r];
+    }
+  }
+  if (p.act == 1) {
+#pragma unroll
+    for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT_PIX; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
+  } else if (p.act == 2) {
+#pragma unroll
+    for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT_PIX; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 1.f / (1.f + __expf(-acc[mi][ni][r]));
+  }
+
+  float s1[NT_CO][4], s2[NT_CO][4];
+#pragma unroll
+  for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
+
+  T* const yb = (T*)p.y + (long)blockIdx.z * p.Ho * p.Wo * p.ldy;
+  const bool interior = oh0 + TH <= p.Ho && ow0 + TW <= p.Wo && n0 + BN <= p.Cout && !p.accumulate;   // wave-uniform
+  if (interior) {
+    T* const d0 = yb + ((long)(oh0 + pt0 / TWT) * p.Wo + ow0 + (pt0 % TWT) * 16 + l15) * p.ldy + n0 + 4 * lg;
+#pragma unroll
+    for (int ni = 0; ni < NT_PIX; ++ni) {
+      const int pt = pt0 + ni;
+      T* dst = d0 + (long)(((pt / TWT) - (pt0 / TWT)) * p.Wo + ((pt % TWT) - (pt0 % TWT)) * 16) * p.ldy;   // uniform offset
+#pragma unroll
+      for (int mi = 0; mi < NT_CO; ++mi) {
+        f32x4 v = acc[mi][ni];
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<f32x4*>(dst + mi * 16) = v;
+        } else {
+          const u32x2 o = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(dst + mi * 16) = o;
+          if (p.stats) v = f32x4{bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1])};   // statistics of the STORED values
+        }
+        if (p.stats) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[mi][r] += v[r]; s2[mi][r] = fmaf(v[r], v[r], s2[mi][r]); }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < NT_PIX; ++ni) {
+      const int pt = pt0 + ni;
+      const int oh = oh0 + pt / TWT, ow = ow0 + (pt % TWT) * 16 + l15;
+      const bool valid = oh < p.Ho && ow < p.Wo;
+      T* dst = yb + ((long)oh * p.Wo + ow) * p.ldy;
+#pragma unroll
+      for (int mi = 0; mi < NT_CO; ++mi) {
+        const int co = n0 + mi * 16 + 4 * lg;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r];
+        if (valid && co + 3 < p.Cout) {
+          if constexpr (sizeof(T) == 4) {
+            f32x4* d4 = reinterpret_cast<f32x4*>(dst + co);
+            f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
+            if (p.accumulate) o += *d4;
+            *d4 = o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = o[r];
+          } else {
+            u32x2* d2 = reinterpret_cast<u32x2*>(dst + co);
+            if (p.accumulate) {
+              const u32x2 old = *d2;
+              v[0] += bflo(old[0]); v[1] += bfhi(old[0]); v[2] += bflo(old[1]); v[3] += bfhi(old[1]);
+            }
+            const u32x2 o = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *d2 = o;
+            v[0] = bflo(o[0]); v[1] = bfhi(o[0]); v[2] = bflo(o[1]); v[3] = bfhi(o[1]);
+          }
+        } else if (valid && co < p.Cout) {   // last, partial group of 4 channels
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (co + r < p.Cout) {
+              if (p.accumulate) v[r] += Elem<T>::ld(dst + co + r);
+              Elem<T>::st(dst + co + r, v[r]);
+              v[r] = Elem<T>::rnd(v[r]);
+            } else {
+              v[r] = 0.f;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[mi][r] += v[r]; s2[mi][r] = fmaf(v[r], v[r], s2[mi][r]); }
+      }
+    }
+  }
+
+  if (p.stats) {  // uniform
+    __syncthreads();  // all fragment reads done: LDS is reused for the cross-wave reduction
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN]
+#pragma unroll
+    for (int mi = 0; mi < NT_CO; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(s1[mi][r]), c2 = row16_sum(s2[mi][r]);   // over the 16 pixels of the MFMA tile (DPP)
+        if (l15 == 0) {
+          const int m = mi * 16 + 4 * lg + r;
+          red[(wave * 2 + 0) * BN + m] = a;
+          red[(wave * 2 + 1) * BN + m] = c2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, m = tid - which * BN;
+      if (n0 + m < p.Cout) {
+        const float tot = red[(0 * 2 + which) * BN + m] + red[(1 * 2 + which) * BN + m] +
+                          red[(2 * 2 + which) * BN + m] + red[(3 * 2 + which) * BN + m];
+        atomicAdd(p.stats + (long)((blockIdx.x + blockIdx.z) % p.nrep) * p.rep_stride + ((long)grp * 2 + which) * p.stats_ld + n0 + m, (double)tot);
+      }
+    }
+  }
+}
+
+template <typename T, int TH, int TW, int BN, int KS>
+int launch_fast(const FastArgs& a, size_t lds, hipStream_t s) {
+  auto kern = conv_fast_kernel<T, TH, TW, BN, KS>;
+  static bool attr_set = false;  // per instantiation
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv_fast: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  dim3 grid(sdhip_cdiv(a.Ho, TH) * sdhip_cdiv(a.Wo, TW), sdhip_cdiv(a.Mpad, BN), a.B * a.Do);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+template <typename T, int TH, int TW, int KS>
+int launch_fast_bn(const FastArgs& a, int bn, size_t lds, hipStream_t s) {
+  switch (bn) {
+    case 16: return launch_fast<T, TH, TW, 16, KS>(a, lds, s);
+    case 32: return launch_fast<T, TH, TW, 32, KS>(a, lds, s);
+    case 64: return launch_fast<T, TH, TW, 64, KS>(a, lds, s);
+    default: return launch_fast<T, TH, TW, 128, KS>(a, lds, s);
+  }
+}
+
+template <typename T>
+int launch_fast_any(const FastArgs& a, bool big, int ks, int bn, size_t lds, hipStream_t s) {
+  if (big) return ks == 2 ? launch_fast_bn<T, 8, 32, 2>(a, bn, lds, s) : launch_fast_bn<T, 8, 32, 1>(a, bn, lds, s);
+  return ks == 2 ? launch_fast_bn<T, 4, 16, 2>(a, bn, lds, s) : launch_fast_bn<T, 4, 16, 1>(a, bn, lds, s);
+}
+
+}  // namespace

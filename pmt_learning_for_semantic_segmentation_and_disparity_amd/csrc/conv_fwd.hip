@@ -15,6 +15,7 @@
 // precedes the conv) and epilogue (bias, activation, accumulate, per-channel
 // sum / sum-of-squares for the BatchNorm that follows).
 #include "conv_common.h"
+#include "conv_fast.h"
 
 namespace {
 
@@ -447,7 +448,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   int bn = a.Mpad > 64 ? 128 : (a.Mpad > 32 ? 64 : (a.Mpad > 16 ? 32 : 16));
   const int T = kh * kw;
   const long blocks_big = (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) * B * Do * sdhip_cdiv(a.Mpad, bn);
-  bool big = blocks_big >= 512 && Wo >= 24;
+  bool big = (blocks_big >= 512 && Wo >= 24) || getenv("SDHIP_CONV_BIG");
   if (!big) {
     // small feature maps (DenseNet blocks 2-4, pooled pyramids): the launch cannot fill 256 CUs with pixel tiles alone,
     // so split the output channels over more workgroups (the input tile is re-read from L2, the serial
@@ -459,9 +460,42 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   const size_t kMax = 160 * 1024, kSoft = 80 * 1024;   // kSoft: two workgroups per CU
   const int CKh = (dtype == SDHIP_BF16 ? 64 : 32);
   const int chunks_per_row = Cin <= CKh / 2 ? 4 : 8;
+  hipStream_t s = (hipStream_t)stream;
+  const int per_tap_any = (kh > 1 || kw > 1) && dil >= 4 && kd == 1;
+  // ---- fast path (conv_fast.h): 16-byte-aligned pixels on both sides, halo-tile mode ----
+  if (!per_tap_any && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && a.vec_out &&
+      (long)H * W * ldx < (1L << 31) && !getenv("SDHIP_CONV_GENERIC")) {
+    const int ks = chunks_per_row == 4 ? 1 : 2;
+    const int rb = 64 * ks, px_per_round = 256 / (4 * ks);
+    FastArgs f;
+    f.x = x; f.wp = wpacked; f.y = y; f.bias = bias; f.in_scale = in_scale; f.in_shift = in_shift; f.stats = stats;
+    f.B = B; f.H = H; f.W = W; f.Ho = Ho; f.Wo = Wo; f.kh = kh; f.kw = kw; f.stride = stride; f.dil = dil; f.pad_t = pad_t; f.pad_l = pad_l;
+    f.D = D; f.Do = Do; f.kd = kd; f.sd = sd; f.pad_d = pad_d;
+    f.Cin = Cin; f.ldx = ldx; f.Cout = Cout; f.Mpad = a.Mpad; f.ldy = ldy;
+    f.in_relu = in_relu; f.bpg = B / groups; f.act = act; f.accumulate = accumulate;
+    f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride; f.tail = (Cin % V) != 0;
+    f.dma = !in_scale && !f.tail;
+    bool fbig = big;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      const int th = fbig ? 8 : 4, tw = fbig ? 32 : 16;
+      const int IH = (th - 1) * stride + (kh - 1) * dil + 1, IW = (tw - 1) * stride + (kw - 1) * dil + 1;
+      const int IWp = (IW + 7) & ~7;
+      const int hrows = ((IH * IWp + px_per_round - 1) / px_per_round) * px_per_round;   // whole load rounds
+      const size_t hb = (size_t)hrows * rb * (fbig ? 1 : 2);
+      if (!fbig && hrows > 5 * px_per_round) { fbig = true; continue; }   // small-tile halo prefetch plan: 5 rounds
+      auto wbuf = [&](int tgv) { return (size_t)(((tgv * bn + px_per_round - 1) / px_per_round) * px_per_round) * rb; };
+      int tg = T;
+      while (tg > 1 && hb + 2 * wbuf(tg) > kSoft) --tg;
+      size_t lds = hb + 2 * wbuf(tg);
+      if (lds < 4096) lds = 4096;
+      if (lds > kMax) { if (!fbig) break; fbig = false; continue; }
+      f.tg = tg;
+      return dtype == SDHIP_BF16 ? launch_fast_any<bf16_t>(f, fbig, ks, bn, lds, s) : launch_fast_any<float>(f, fbig, ks, bn, lds, s);
+    }
+  }
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int th = big ? 8 : 4, tw = big ? 32 : 16;
-    const int per_tap = (kh > 1 || kw > 1) && dil >= 4 && kd == 1;   // halo would be >= 4x the tile in each direction's holes
+    const int per_tap = per_tap_any;   // halo would be >= 4x the tile in each direction's holes
     const size_t halo = halo_bytes_of(a.g, th, tw, per_tap);
     const long halo_loads = (long)(halo / 128) * chunks_per_row;
     // register-prefetched (double-buffered) halo: small tiles, at most 4 loads per lane, vector loads only
@@ -479,7 +513,6 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
       SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd: halo tile of a %dx%d kernel with dilation %d does not fit LDS", kh, kw, dil);
     }
     a.tg = tg; a.pf_halo = pf; a.sh = chunks_per_row == 4 ? 2 : 3; a.per_tap = per_tap;
-    hipStream_t s = (hipStream_t)stream;
     if (dtype == SDHIP_BF16)
       return big ? launch_bn<bf16_t, 8, 32>(a, bn, lds, s) : launch_bn<bf16_t, 4, 16>(a, bn, lds, s);
     return big ? launch_bn<float, 8, 32>(a, bn, lds, s) : launch_bn<float, 4, 16>(a, bn, lds, s);

@@ -35,10 +35,16 @@ struct FastArgs {
 __device__ __attribute__((aligned(16))) unsigned int sdhip_zero16[4] = {0u, 0u, 0u, 0u};
 
 // one global_load_lds_dwordx4: the wave's 64 lanes fetch 16 bytes each from their own address and the hardware writes
-// them to lds_wave_base + lane*16 (no VGPR destination; completion is tracked by vmcnt)
-__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// them to LDS byte address lds_wave_base + lane*16 (no VGPR destination; completion is tracked by vmcnt).
+// Issued as inline asm on purpose: when hipcc sees an LDS-DMA in flight it puts `s_waitcnt vmcnt(0)` in front of every
+// following ds_read it cannot prove disjoint (all of them, with dynamic LDS offsets), which would serialise the
+// prefetch of stage s+1 with the fragment reads of stage s.  The kernel waits for its DMA explicitly before the
+// barrier that publishes a stage instead.
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_wave_base) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
 
 // sum over the 16 lanes of a DPP row (the 16 pixels of one MFMA output tile); every lane gets the total.
@@ -61,7 +67,10 @@ template <> struct LdsRow<1> {
   static __device__ __forceinline__ int off(int row, int c) { return row * 64 + ((c ^ ((row >> 1) & 2)) << 4); }
 };
 
-template <typename T, int TH, int TW, int BN, int KS>
+// DMA: the halo tile goes global -> LDS by LDS-DMA (no BatchNorm prologue, no odd channel tail); otherwise through
+// registers with the prologue applied on the way.  Two instantiations, so that the DMA variant contains no ordinary
+// global load at all inside its stage loop (hipcc would wait for it — and with it for the DMA — in the MFMA loop).
+template <typename T, int TH, int TW, int BN, int KS, bool DMA>
 __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   constexpr int V = Chunk<T>::N;          // elements per 16 bytes
   constexpr int CK = 8 * V;               // channels per packed weight row (always 128 bytes)
@@ -129,9 +138,9 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   const int rsub = tid >> SH;
   const int c_l = (tid & (CH - 1)) ^ (KS == 2 ? (rsub & 6) : ((rsub >> 1) & 2));   // logical chunk this lane fetches
   const int tid16 = tid * 16;
-  const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
+  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);   // LDS byte address of this wave's KiB in round 0 of smem
   const unsigned magic_iwp = div_magic(IWp);
-  const bool dma = p.dma;
+  constexpr bool dma = DMA;
   const int h_rows = IH * IWp;
   const int h_rounds = (h_rows + RPR - 1) / RPR;
   int h_src[HPF];     // small tiles: element offset of the lane's chunk inside one depth slice per round, or -1 (padding)
@@ -161,17 +170,28 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     }
     return raw;
   };
-  auto prologue = [&](u32x4 raw, int ch0) -> u32x4 {     // BatchNorm affine (+ReLU) of the producer, fused on load
+  // BatchNorm affine (+ReLU) of the producer, fused on load.  A lane's channel offset inside a chunk is fixed, so its
+  // 2*V scale/shift values are fetched once per chunk (four 16-byte loads), not once per pixel.
+  float psc[V], psf[V];
+  auto prologue_load = [&](int ch0) {
+    if (ch0 < p.Cin) {   // Cin % V == 0 whenever a prologue is fused (host: the tail path never carries one)
+      const float* sc = p.in_scale + grp * p.Cin + ch0;
+      const float* sf = p.in_shift + grp * p.Cin + ch0;
+#pragma unroll
+      for (int e = 0; e < V; e += 4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(sc + e), b4 = *reinterpret_cast<const f32x4*>(sf + e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { psc[e + i] = a4[i]; psf[e + i] = b4[i]; }
+      }
+    }
+  };
+  auto prologue = [&](u32x4 raw) -> u32x4 {
     float f[V];
     Chunk<T>::unpack(raw, f);
-    const float* sc = p.in_scale + grp * p.Cin + ch0;
-    const float* sf = p.in_shift + grp * p.Cin + ch0;
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      if (ch0 + e < p.Cin) {
-        const float v = fmaf(f[e], sc[e], sf[e]);
-        f[e] = p.in_relu ? fmaxf(v, 0.f) : v;
-      }
+      const float v = fmaf(f[e], psc[e], psf[e]);
+      f[e] = p.in_relu ? fmaxf(v, 0.f) : v;
     }
     return Chunk<T>::pack(f);
   };
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     for (int j = 0; j < HPF; ++j) {
       if (j < h_rounds) {
         const T* src = (ok && h_src[j] >= 0) ? xb + h_src[j] : (const T*)sdhip_zero16;
-        if (dma) glds16(src, dst + j * 4096 + wave_lds);
+        if constexpr (dma) glds16(src, (unsigned)(dst - smem) + j * 4096 + wave_lds);
         else rh[j] = *reinterpret_cast<const u32x4*>(src);
       }
     }
@@ -195,13 +215,14 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     const int ch0 = (qq % nq) * CKS + c_l * V;
     const int din = slice_of(qq);
     const bool ok = din >= 0 && din < p.D && ch0 < p.Cin;
+    if (p.in_scale) prologue_load(ch0);
 #pragma unroll
     for (int j = 0; j < HPF; ++j) {
       if (j < h_rounds) {
         u32x4 raw = rh[j];
         if (ok && h_src[j] >= 0) {
           if (p.tail) raw = mask_tail(raw, ch0);
-          if (p.in_scale) raw = prologue(raw, ch0);
+          if (p.in_scale) raw = prologue(raw);
         }
         *reinterpret_cast<u32x4*>(dst + j * 4096 + tid16) = raw;
       }
@@ -220,23 +241,26 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
       const bool in = ok && iw < IW && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
       return in ? xb + (gh * p.W + gw) * p.ldx : (const T*)sdhip_zero16;
     };
-    if (dma) {
-      for (int j = 0; j < h_rounds; ++j) glds16(src_of(j), dst + j * 4096 + wave_lds);
+    if constexpr (dma) {
+      for (int j = 0; j < h_rounds; ++j) glds16(src_of(j), (unsigned)(dst - smem) + j * 4096 + wave_lds);
     } else {
+      if (p.in_scale) prologue_load(ch0);
       for (int j0 = 0; j0 < h_rounds; j0 += 4) {
         u32x4 raw[4];
         bool in[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const T* src = src_of(min(j0 + j, h_rounds - 1));
-          in[j] = src != (const T*)sdhip_zero16;
-          raw[j] = *reinterpret_cast<const u32x4*>(src);
+          if (j0 + j < h_rounds) {   // uniform; never leave an unconsumed load pending (it would be waited for in the MFMA loop)
+            const T* src = src_of(j0 + j);
+            in[j] = src != (const T*)sdhip_zero16;
+            raw[j] = *reinterpret_cast<const u32x4*>(src);
+          }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (j0 + j < h_rounds) {
             if (in[j] && p.tail) raw[j] = mask_tail(raw[j], ch0);
-            if (in[j] && p.in_scale) raw[j] = prologue(raw[j], ch0);
+            if (in[j] && p.in_scale) raw[j] = prologue(raw[j]);
             *reinterpret_cast<u32x4*>(dst + (j0 + j) * 4096 + tid16) = raw[j];
           }
         }
@@ -246,30 +270,47 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   // weights of stage (chunk qq, taps t0..): always LDS-DMA, issued right after the barrier that retired the buffer.
   // Rows of output channels past Mpad (last block) and taps past the kernel are never used by a stored result: they
   // re-read row 0 of the stage instead of being zero-filled.
+  constexpr int RPT = BN >= RPR ? BN / RPR : 1;   // load rounds per tap
+  constexpr int TPR = BN >= RPR ? 1 : RPR / BN;   // taps per load round (narrow blocks)
   auto w_issue = [&](int qq, int t0, unsigned char* dst) {   // packed weights are [kd][nq][T][Mpad][CK]
     const int nt = min(p.tg, Tn - t0);
     const T* base = wpk + ((long)(qq * Tn + t0) * p.Mpad + n0) * CK + c_l * V;
-    for (int j = 0; j < w_rounds; ++j) {
-      const int row = rsub + j * RPR;
-      const int tl = row / BN, m = row - tl * BN;   // BN is a power of two
-      const int off = (tl < nt && m < mvalid) ? (tl * p.Mpad + m) * CK : 0;
-      glds16(base + off, dst + j * 4096 + wave_lds);
+    unsigned lds = (unsigned)(dst - smem) + wave_lds;
+    if constexpr (BN >= RPR) {
+      for (int tl = 0; tl < nt; ++tl) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          const int m = min(r * RPR + rsub, mvalid - 1);
+          glds16(base + (tl * p.Mpad + m) * CK, lds);
+          lds += 4096;
+        }
+      }
+    } else {
+      const int m = min(rsub % BN, mvalid - 1);
+      for (int t = 0; t < nt; t += TPR) {
+        const int tl = min(t + rsub / BN, nt - 1);
+        glds16(base + (tl * p.Mpad + m) * CK, lds);
+        lds += 4096;
+      }
     }
   };
 
   // ---- the MFMA steps of one stage: (tap, k-step) pairs, two fragment register sets ----
+  // tap walk state (wave-uniform), carried across the stages of a chunk: halo-row offset of the current tap
+  int kwi = 0, tap_off = 0;
+  const int tap_row_step = d * IWp - p.kw * d;
   auto compute = [&](int t0, const unsigned char* halo, const unsigned char* wl) {
     const int nt = min(p.tg, Tn - t0);
     const int n = nt * KS;
-    int khi = t0 / p.kw, kwi = t0 - khi * p.kw;
     u32x4 af[2][NT_CO], bf[2][NT_PIX];
     int b_addr = 0, a_addr = 0;
     auto next_tap = [&](int tl) {   // fragment byte addresses of tap tl of the group, k-step 0, pixel tile 0 / cout tile 0
-      const int row = prow0 + (khi * d) * IWp + kwi * d;
+      const int row = prow0 + tap_off;
       if constexpr (KS == 2) b_addr = row * RB + (lg4 ^ ((row & 6) << 4));
       else b_addr = row * RB + (lg4 ^ (((row >> 1) & 2) << 4));
       a_addr = a_base + tl * (BN * RB);
-      if (++kwi == p.kw) { kwi = 0; ++khi; }
+      tap_off += d;                                            // next tap of the kernel row ...
+      if (++kwi == p.kw) { kwi = 0; tap_off += tap_row_step; }  // ... or first tap of the next kernel row
     };
     auto load = [&](int set, int ks) {
       const unsigned char* ab = wl + (a_addr ^ (ks << 6));
@@ -317,8 +358,8 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     const int t0 = tgi * p.tg;
     unsigned char* halo = halo0 + ((PF && (q & 1)) ? halo_bytes : 0);
     unsigned char* wl = wl0 + (st & 1) * wbuf_bytes;
-    if (PF && !dma && tgi == 0) halo_commit(q, halo);
-    // hipcc does not reliably drain LDS-DMA before a barrier reached over the loop back edge: wait explicitly
+    if constexpr (PF && !dma) { if (tgi == 0) halo_commit(q, halo); }
+    // the DMA (inline asm, invisible to the compiler's wait-count pass) of this stage must have landed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                      // stage st is visible (DMA drained); every wave has finished stage st-1
     int qn = q, tgn = tgi + 1;
@@ -330,9 +371,11 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     }
     compute(t0, halo, wl);
     if (!PF && more && tgn == 0) {        // chunk boundary with a single (large) halo buffer
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       halo_sync_stage(qn, halo0);
     }
+    if (tgn == 0) { kwi = 0; tap_off = 0; }   // next chunk starts at tap (0,0) again
     q = qn; tgi = tgn;
   }
 
@@ -479,9 +522,9 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   }
 }
 
-template <typename T, int TH, int TW, int BN, int KS>
+template <typename T, int TH, int TW, int BN, int KS, bool DMA>
 int launch_fast(const FastArgs& a, size_t lds, hipStream_t s) {
-  auto kern = conv_fast_kernel<T, TH, TW, BN, KS>;
+  auto kern = conv_fast_kernel<T, TH, TW, BN, KS, DMA>;
   static bool attr_set = false;  // per instantiation
   if (lds > 64 * 1024 && !attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -494,20 +537,25 @@ int launch_fast(const FastArgs& a, size_t lds, hipStream_t s) {
   return SDHIP_OK;
 }
 
-template <typename T, int TH, int TW, int KS>
+template <typename T, int TH, int TW, int KS, bool DMA>
 int launch_fast_bn(const FastArgs& a, int bn, size_t lds, hipStream_t s) {
   switch (bn) {
-    case 16: return launch_fast<T, TH, TW, 16, KS>(a, lds, s);
-    case 32: return launch_fast<T, TH, TW, 32, KS>(a, lds, s);
-    case 64: return launch_fast<T, TH, TW, 64, KS>(a, lds, s);
-    default: return launch_fast<T, TH, TW, 128, KS>(a, lds, s);
+    case 16: return launch_fast<T, TH, TW, 16, KS, DMA>(a, lds, s);
+    case 32: return launch_fast<T, TH, TW, 32, KS, DMA>(a, lds, s);
+    case 64: return launch_fast<T, TH, TW, 64, KS, DMA>(a, lds, s);
+    default: return launch_fast<T, TH, TW, 128, KS, DMA>(a, lds, s);
   }
+}
+
+template <typename T, bool DMA>
+int launch_fast_tile(const FastArgs& a, bool big, int ks, int bn, size_t lds, hipStream_t s) {
+  if (big) return ks == 2 ? launch_fast_bn<T, 8, 32, 2, DMA>(a, bn, lds, s) : launch_fast_bn<T, 8, 32, 1, DMA>(a, bn, lds, s);
+  return ks == 2 ? launch_fast_bn<T, 4, 16, 2, DMA>(a, bn, lds, s) : launch_fast_bn<T, 4, 16, 1, DMA>(a, bn, lds, s);
 }
 
 template <typename T>
 int launch_fast_any(const FastArgs& a, bool big, int ks, int bn, size_t lds, hipStream_t s) {
-  if (big) return ks == 2 ? launch_fast_bn<T, 8, 32, 2>(a, bn, lds, s) : launch_fast_bn<T, 8, 32, 1>(a, bn, lds, s);
-  return ks == 2 ? launch_fast_bn<T, 4, 16, 2>(a, bn, lds, s) : launch_fast_bn<T, 4, 16, 1>(a, bn, lds, s);
+  return a.dma ? launch_fast_tile<T, true>(a, big, ks, bn, lds, s) : launch_fast_tile<T, false>(a, big, ks, bn, lds, s);
 }
 
 }  // namespace

@@ -89,6 +89,13 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const StageSrc& s
         const T* src = xb + ((long)gh * s.W + gw) * s.ld + ch[j];
         if (s.vec) {
           raw[j] = *reinterpret_cast<const u32x4*>(src);
+          if (ch[j] + V > s.C) {   // odd channel count inside a padded pixel stride: the chunk's tail is not data
+            float f[V];
+            Chunk<T>::unpack(raw[j], f);
+#pragma unroll
+            for (int e = 0; e < V; ++e) f[e] = (ch[j] + e < s.C) ? f[e] : 0.f;
+            raw[j] = Chunk<T>::pack(f);
+          }
         } else {
           float f[V];
 #pragma unroll

@@ -443,9 +443,12 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   a.stats_ld = stats_ld > 0 ? stats_ld : Cout;
   a.nrep = stats_nrep > 0 ? stats_nrep : 1;
   a.rep_stride = (long)groups * 2 * a.stats_ld;
-  a.vec_in = (Cin % V == 0) && (ldx % V == 0) && (((uintptr_t)x & 15) == 0);
+  a.vec_in = (ldx % V == 0) && (((uintptr_t)x & 15) == 0);   // channel tails are masked in stage_tile
   a.vec_out = (ldy % 4 == 0) && (((uintptr_t)y % (4 * es)) == 0);
-  int bn = a.Mpad > 64 ? 128 : (a.Mpad > 32 ? 64 : (a.Mpad > 16 ? 32 : 16));
+  // output channels per workgroup: the widest block that wastes at most a quarter of its MFMA rows on padding
+  int bn = 16;
+  for (int cand = 128; cand >= 32; cand >>= 1)
+    if ((long)sdhip_cdiv(a.Mpad, cand) * cand * 4 <= (long)a.Mpad * 5) { bn = cand; break; }
   const int T = kh * kw;
   const long blocks_big = (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) * B * Do * sdhip_cdiv(a.Mpad, bn);
   bool big = (blocks_big >= 512 && Wo >= 24) || getenv("SDHIP_CONV_BIG");
@@ -499,7 +502,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
     const size_t halo = halo_bytes_of(a.g, th, tw, per_tap);
     const long halo_loads = (long)(halo / 128) * chunks_per_row;
     // register-prefetched (double-buffered) halo: small tiles, at most 4 loads per lane, vector loads only
-    const int pf = !per_tap && !big && a.vec_in && halo_loads <= 4 * 256 && 2 * halo + 2 * (size_t)bn * 128 <= kSoft;
+    const int pf = !per_tap && !big && a.vec_in && (Cin % V == 0) && halo_loads <= 4 * 256 && 2 * halo + 2 * (size_t)bn * 128 <= kSoft;
     // weights: at most 4 loads per lane per stage => tg*rows*chunks_per_row <= 1024
     int tg = per_tap ? 1 : 1024 / (rows * chunks_per_row);
     if (tg < 1) tg = 1;

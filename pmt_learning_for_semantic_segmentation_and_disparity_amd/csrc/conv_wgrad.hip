@@ -381,8 +381,8 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
   a.ntg = sdhip_cdiv(T, maxt);
   a.tpb = sdhip_cdiv(T, a.ntg);              // balanced tap groups (49 -> 25, 24)
   a.ntg = sdhip_cdiv(T, a.tpb);
-  a.vec_x = (Cin % V == 0) && (ldx % V == 0) && (((uintptr_t)x & 15) == 0);
-  a.vec_dy = (Cout % V == 0) && (lddy % V == 0) && (((uintptr_t)dy & 15) == 0);
+  a.vec_x = (ldx % V == 0) && (((uintptr_t)x & 15) == 0);      // channel tails are masked in stage_tile
+  a.vec_dy = (lddy % V == 0) && (((uintptr_t)dy & 15) == 0);
   hipStream_t s = (hipStream_t)stream;
   const long n = (long)kd * sdhip_conv_packed_elems(Cout, Cin, T, dtype);
   if (!prezeroed) {

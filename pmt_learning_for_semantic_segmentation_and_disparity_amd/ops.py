@@ -38,6 +38,17 @@ def empty_nhwc(B, C, H, W, dtype, device):
     return torch.empty((B, H, W, C), dtype=dtype, device=device).permute(0, 3, 1, 2)
 
 
+def alloc_nhwc(B, C, H, W, dtype, device):
+    """(tensor, ld): NHWC tensor whose pixel stride is rounded up to 8 elements (16 bytes of bf16), so that tensors
+    with odd channel counts (the 65-channel concats, 1-channel maps of models/dsnet_t2.py:1128-1170) still take the
+    16-byte vector / LDS-DMA paths of the conv kernels.  The pad channels are never read as data (the kernels mask
+    the channel tail) and never written."""
+    ld = (C + 7) & ~7
+    if ld == C:
+        return empty_nhwc(B, C, H, W, dtype, device), C
+    return torch.empty((B, H, W, ld), dtype=dtype, device=device)[..., :C].permute(0, 3, 1, 2), ld
+
+
 class _CorrFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, in1, in2, PH, PW, dil):
@@ -361,7 +372,7 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
     gpost = gw = gb = None
     if need_x:
         wd = packed_weight(weight, spec.kind, 'dgrad', xv.dtype)
-        gpost = empty_nhwc(Bimg, Cin, H, W, xv.dtype, xv.device)
+        gpost, ldgp = alloc_nhwc(Bimg, Cin, H, W, xv.dtype, xv.device)
         pt = spec.dil * (spec.kh - 1) - spec.pad_t
         pl = spec.dil * (spec.kw - 1) - spec.pad_l
         pd = (spec.kd - 1) - spec.pad_d
@@ -373,7 +384,7 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
             call("sdhip_stuff", ptr(g), ldg, ptr(gsrc), Cout, B, spec.Do, spec.Ho, spec.Wo, Cout, spec.sd, spec.stride, 1, dt,
                  stream_ptr())
             ldsrc = Cout
-        _conv_launch(gsrc, ldsrc, wd, gpost, Cin, None, None, None, None, B, Hg, Wg, Cout, H, W, Cin,
+        _conv_launch(gsrc, ldsrc, wd, gpost, ldgp, None, None, None, None, B, Hg, Wg, Cout, H, W, Cin,
                      spec.kh, spec.kw, 1, spec.dil, pt, pl, False, 1, 0, False, 1, (Dg, spec.D, spec.kd, 1, pd))
     if need_w:
         gw, gb = wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu, groups)
@@ -445,8 +456,8 @@ class _ConvFn(torch.autograd.Function):
         xv, ldx = nhwc_view(x)
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
         wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
-        y = empty_nhwc(B * spec.Do, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
-        _conv_launch(xv, ldx, wp, y, Cout, bias.detach() if bias is not None else None, None, None, None, B, H, W, Cin,
+        y, ldy = alloc_nhwc(B * spec.Do, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
+        _conv_launch(xv, ldx, wp, y, ldy, bias.detach() if bias is not None else None, None, None, None, B, H, W, Cin,
                      spec.Ho, spec.Wo, Cout, spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, 1, act, False,
                      1, spec.depth())
         ctx.spec, ctx.act, ctx.ldx = spec, act, ldx
@@ -461,10 +472,10 @@ class _ConvFn(torch.autograd.Function):
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
         g, ldg = nhwc_view(gy)
         if act:   # activation fused in the epilogue: derivative from the stored output
-            g2 = empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
-            call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(ysaved), Cout, ptr(g2), Cout, None, None, None, None, 1,
+            g2, ldg2 = alloc_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
+            call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(ysaved), nhwc_view(ysaved)[1], ptr(g2), ldg2, None, None, None, None, 1,
                  B * spec.Ho * spec.Wo, Cout, 1, 1 if act == 1 else 4, 0, 0, dtype_code(xv), stream_ptr())
-            g, ldg = g2, Cout
+            g, ldg = g2, ldg2
         gx, gw, gb = _conv_backward(spec, xv, ctx.ldx, weight, g, ldg, None, None, False, 1, ctx.needs_input_grad[0],
                                     ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]), bias)
         return gx, gw, gb, None, None
@@ -484,18 +495,19 @@ class _ConvBNActFn(torch.autograd.Function):
         xv, ldx = nhwc_view(x)
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
         wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
-        yraw = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
+        yraw, ldr_ = alloc_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
         train = bn.training
         ws = _zeros((NREP, groups, 2, Cout), torch.float64, x.device)[0] if train else None
-        _conv_launch(xv, ldx, wp, yraw, Cout, None, None, None, ws, Btrue, H, W, Cin, spec.Ho, spec.Wo, Cout,
+        _conv_launch(xv, ldx, wp, yraw, ldr_, None, None, None, ws, Btrue, H, W, Cin, spec.Ho, spec.Wo, Cout,
                      spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, groups, 0, False, NREP, spec.depth())
         count = (B // groups) * spec.Ho * spec.Wo
         scale, shift, mean, invstd = _bn_finalize(ws, NREP, bn, count, groups)
         rv, ldr = nhwc_view(residual) if residual is not None else (None, 0)
-        y = empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
-        call("sdhip_affine_act", ptr(yraw), Cout, ptr(y), Cout, ptr(rv), ldr, ptr(scale), ptr(shift), B * spec.Ho * spec.Wo,
+        y, ldy = alloc_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
+        call("sdhip_affine_act", ptr(yraw), ldr_, ptr(y), ldy, ptr(rv), ldr, ptr(scale), ptr(shift), B * spec.Ho * spec.Wo,
              Cout, groups, act, dtype_code(x), stream_ptr())
         ctx.spec, ctx.act, ctx.groups, ctx.ldx, ctx.count, ctx.train = spec, act, groups, ldx, count, train
+        ctx.ldraw = ldr_
         ctx.has_res = residual is not None
         ctx.save_for_backward(xv, weight, gamma, beta, yraw, scale, shift, mean, invstd)
         return y
@@ -509,13 +521,14 @@ class _ConvBNActFn(torch.autograd.Function):
         npix = B * spec.Ho * spec.Wo
         dt = dtype_code(xv)
         g, ldg = nhwc_view(gy)
-        graw = empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
-        dgamma, dbeta, dS = _bn_backward(g, ldg, yraw, Cout, graw, Cout, scale, shift, mean, invstd, gamma, npix, Cout,
+        graw, ldgr = alloc_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
+        ldraw = ctx.ldraw
+        dgamma, dbeta, dS = _bn_backward(g, ldg, yraw, ldraw, graw, ldgr, scale, shift, mean, invstd, gamma, npix, Cout,
                                          groups, ctx.act, ctx.count, ctx.train, dt, beta=beta)
         if ctx.train:
-            call("sdhip_stats_fix", ptr(graw), Cout, ptr(yraw), Cout, ptr(graw), Cout, ptr(dS), Cout, npix, Cout, groups,
+            call("sdhip_stats_fix", ptr(graw), ldgr, ptr(yraw), ldraw, ptr(graw), ldgr, ptr(dS), Cout, npix, Cout, groups,
                  dt, stream_ptr())
-        gx, gw, _ = _conv_backward(spec, xv, ctx.ldx, weight, graw, Cout, None, None, False, 1, ctx.needs_input_grad[0],
+        gx, gw, _ = _conv_backward(spec, xv, ctx.ldx, weight, graw, ldgr, None, None, False, 1, ctx.needs_input_grad[0],
                                    ctx.needs_input_grad[1])
         return gx, gw, dgamma, dbeta, (gy if ctx.has_res else None), None, None, None, None
 
@@ -550,8 +563,8 @@ class _BNConvFn(torch.autograd.Function):
         g, ldg = nhwc_view(gy)
         gpost, gw, _ = _conv_backward(spec, xv, ctx.ldx, weight, g, ldg, scale, shift, True, groups, True, True)
         gx = empty_nhwc(B, Cin, H, W, xv.dtype, xv.device)
-        dgamma, dbeta, dS = _bn_backward(gpost, Cin, xv, ctx.ldx, gx, Cin, scale, shift, mean, invstd, gamma, B * H * W, Cin,
-                                         groups, 1, ctx.count, ctx.train, dt, beta=beta)
+        dgamma, dbeta, dS = _bn_backward(gpost, nhwc_view(gpost)[1], xv, ctx.ldx, gx, Cin, scale, shift, mean, invstd, gamma,
+                                         B * H * W, Cin, groups, 1, ctx.count, ctx.train, dt, beta=beta)
         return gx, (dS if ctx.train else None), gw, dgamma, dbeta, None, None, None
 
 
@@ -792,13 +805,13 @@ class _ConcatFn(torch.autograd.Function):
         _require_gpu(*xs)
         B, _, H, W = xs[0].shape
         Ct = sum(t.shape[1] for t in xs)
-        out = empty_nhwc(B, Ct, H, W, xs[0].dtype, xs[0].device)
+        out, ldo = alloc_nhwc(B, Ct, H, W, xs[0].dtype, xs[0].device)
         off, offs = 0, []
         for t in xs:
             C = t.shape[1]
             tv, ld = nhwc_view(t)
             dst = out[:, off:off + C]
-            call("sdhip_affine_act", ptr(tv), ld, ptr(dst), Ct, None, 0, None, None, B * H * W, C, 1, 0, dtype_code(t), stream_ptr())
+            call("sdhip_affine_act", ptr(tv), ld, ptr(dst), ldo, None, 0, None, None, B * H * W, C, 1, 0, dtype_code(t), stream_ptr())
             offs.append((off, C))
             off += C
         ctx.offs = offs
@@ -892,8 +905,10 @@ class _TrainLossFn(torch.autograd.Function):
             call("sdhip_ce_loss", ptr(sv), ld, ptr(tv), ldt, ptr(g), C, ptr(loss), npix, C, 1.0, dt, stream_ptr())
             grads.append(g)
         dv, ldd = nhwc_view(disp)
-        if ldd != 1 or not disp_t.is_contiguous():
-            raise _lib.SdhipError("disparity tensors must be dense (B,1,H,W)")
+        if ldd != 1:      # 1-channel map inside a padded pixel stride (direct conv output): densify
+            dv = disp.contiguous()
+        if not disp_t.is_contiguous():
+            raise _lib.SdhipError("disparity target must be a dense (B,1,H,W) tensor")
         gd = torch.empty_like(dv)
         call("sdhip_l1_loss", ptr(dv), ptr(disp_t), ptr(gd), ptr(loss), npix, 1.0, dt, stream_ptr())
         if use_lovasz:   # added onto the CE gradient of seg2 in place

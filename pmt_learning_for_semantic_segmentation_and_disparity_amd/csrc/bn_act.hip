@@ -235,41 +235,58 @@ __global__ void bn_finalize_kernel(const double* __restrict__ S, int ldc, int nr
   if (rmean) { rmean[c] = rm; rvar[c] = rv; }
 }
 
-// (dscale, dshift)[G][C] -> dgamma[C], dbeta[C] (summed over groups), dS[G][2][C]
-__global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift, int nrep,
+// (dscale, dshift)[rep][G][C] -> dgamma[C], dbeta[C] (summed over groups), dS[G][2][C]
+// One workgroup = 32 channels x 8 replica lanes: every thread sums nrep/8 replicas (independent loads, one round trip),
+// the 8 partials meet in LDS.  (A single thread per channel walking 32 replicas made this per-layer kernel a 17 us
+// latency chain on the backward critical path.)
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift, int nrep,
                                        const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, double* __restrict__ dS, int ldc, int acc_flags,
-                                       int C, int G, double count, int train) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float gm = gamma ? gamma[c] : 1.f;
+                                       int C, int G, double inv_count, int train) {
+  __shared__ float red[2][8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const bool okc = c < C;
   const int acc_ds = acc_flags & 1, acc_par = acc_flags & 2;   // bit 0: dstats += ; bit 1: dgamma/dbeta +=
   float dg = 0.f, db = 0.f;
   for (int g = 0; g < G; ++g) {
     float ds = 0.f, dh = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < nrep; ++r) { ds += dscale[((long)r * G + g) * C + c]; dh += dshift[((long)r * G + g) * C + c]; }
-    const float mu = mean[g * C + c], inv = invstd[g * C + c];
-    const float t = ds - mu * dh;       // d/d(gamma*invstd) collected
-    dg += inv * t;
-    db += dh;
-    if (dS) {
-      if (train) {
-        const double dinv = (double)gm * t;
-        const double dvar = -0.5 * dinv * (double)inv * inv * inv;
-        const double dmu = -(double)gm * inv * dh - 2.0 * mu * dvar;
-        double* d0 = dS + ((long)g * 2 + 0) * ldc + c;
-        double* d1 = dS + ((long)g * 2 + 1) * ldc + c;
-        *d0 = (acc_ds ? *d0 : 0.) + dmu / count;
-        *d1 = (acc_ds ? *d1 : 0.) + dvar / count;
-      } else if (!acc_ds) {
-        dS[((long)g * 2 + 0) * ldc + c] = 0.;
-        dS[((long)g * 2 + 1) * ldc + c] = 0.;
+    if (okc) {
+#pragma unroll 4
+      for (int r = rl; r < nrep; r += 8) { ds += dscale[((long)r * G + g) * C + c]; dh += dshift[((long)r * G + g) * C + c]; }
+    }
+    __syncthreads();   // previous group's partials are consumed
+    red[0][rl][cl] = ds; red[1][rl][cl] = dh;
+    __syncthreads();
+    if (rl == 0 && okc) {
+      ds = 0.f; dh = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { ds += red[0][r][cl]; dh += red[1][r][cl]; }
+      const float gm = gamma ? gamma[c] : 1.f;
+      const float mu = mean[g * C + c], inv = invstd[g * C + c];
+      const float t = ds - mu * dh;       // d/d(gamma*invstd) collected
+      dg += inv * t;
+      db += dh;
+      if (dS) {
+        if (train) {
+          const double dinv = (double)gm * t;
+          const double dvar = -0.5 * dinv * (double)inv * inv * inv;
+          const double dmu = -(double)gm * inv * dh - 2.0 * mu * dvar;
+          double* d0 = dS + ((long)g * 2 + 0) * ldc + c;
+          double* d1 = dS + ((long)g * 2 + 1) * ldc + c;
+          *d0 = (acc_ds ? *d0 : 0.) + dmu * inv_count;
+          *d1 = (acc_ds ? *d1 : 0.) + dvar * inv_count;
+        } else if (!acc_ds) {
+          dS[((long)g * 2 + 0) * ldc + c] = 0.;
+          dS[((long)g * 2 + 1) * ldc + c] = 0.;
+        }
       }
     }
   }
-  if (dgamma) dgamma[c] = acc_par ? dgamma[c] + dg : dg;
-  if (dbeta) dbeta[c] = acc_par ? dbeta[c] + db : db;
+  if (rl == 0 && okc) {
+    if (dgamma) dgamma[c] = acc_par ? dgamma[c] + dg : dg;
+    if (dbeta) dbeta[c] = acc_par ? dbeta[c] + db : db;
+  }
 }
 
 template <typename T>
@@ -449,8 +466,9 @@ extern "C" int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, i
                                      float* dgamma, float* dbeta, double* dstats, int ldc, int accumulate_dstats,
                                      int C, int groups, double count, int train, void* stream) {
   SDHIP_CHECK_ARG(C > 0 && groups >= 1 && dscale && dshift && mean && invstd, "bn_finalize_bwd: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(sdhip_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, dscale, dshift,
-                     nrep > 0 ? nrep : 1, gamma, mean, invstd, dgamma, dbeta, dstats, ldc > 0 ? ldc : C, accumulate_dstats, C, groups, count, train);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(sdhip_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, dscale, dshift,
+                     nrep > 0 ? nrep : 1, gamma, mean, invstd, dgamma, dbeta, dstats, ldc > 0 ? ldc : C, accumulate_dstats, C, groups,
+                     1.0 / count, train);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }

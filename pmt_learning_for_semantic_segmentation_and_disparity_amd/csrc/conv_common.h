@@ -71,6 +71,19 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const StageSrc& s
   constexpr int CK = 8 * V;
   const int total = (s.IH * s.IW) << sh;
   const T* xb = (const T*)s.base;
+  // The lane's 16-byte chunk inside a pixel is the same for all its loads (NT is a multiple of the chunks per pixel):
+  // its prologue coefficients are fetched ONCE, all loads in flight together (fetched per element inside the loop they
+  // form a chain of dependent global loads — tens of microseconds per tile).
+  float psc[V], psf[V];
+  if (s.scale) {
+    const int chl = q * CK + (tid & ((1 << sh) - 1)) * V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const bool okc = chl + e < s.C;
+      psc[e] = okc ? s.scale[okc ? chl + e : 0] : 0.f;
+      psf[e] = okc ? s.shift[okc ? chl + e : 0] : 0.f;
+    }
+  }
   for (int i0 = tid; i0 < total; i0 += NT * NB) {
     u32x4 raw[NB];
     int ch[NB], off[NB];
@@ -113,7 +126,7 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const StageSrc& s
 #pragma unroll
           for (int e = 0; e < V; ++e) {
             if (ch[j] + e < s.C) {
-              const float v = fmaf(f[e], s.scale[ch[j] + e], s.shift[ch[j] + e]);
+              const float v = fmaf(f[e], psc[e], psf[e]);
               f[e] = s.relu ? fmaxf(v, 0.f) : v;
             }
           }

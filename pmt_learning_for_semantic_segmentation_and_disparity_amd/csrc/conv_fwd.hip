@@ -449,6 +449,8 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   int bn = 16;
   for (int cand = 128; cand >= 32; cand >>= 1)
     if ((long)sdhip_cdiv(a.Mpad, cand) * cand * 4 <= (long)a.Mpad * 5) { bn = cand; break; }
+  // short reductions (1x1 over <= 128 channels ...) are bound by staging the input tile, not by MFMA rows: one pass
+  if ((long)kh * kw * kd * Cin <= 128 && a.Mpad <= 128) bn = a.Mpad > 64 ? 128 : (a.Mpad > 32 ? 64 : (a.Mpad > 16 ? 32 : 16));
   const int T = kh * kw;
   const long blocks_big = (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) * B * Do * sdhip_cdiv(a.Mpad, bn);
   bool big = (blocks_big >= 512 && Wo >= 24) || getenv("SDHIP_CONV_BIG");

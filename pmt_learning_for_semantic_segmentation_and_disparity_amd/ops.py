@@ -49,6 +49,19 @@ def alloc_nhwc(B, C, H, W, dtype, device):
     return torch.empty((B, H, W, ld), dtype=dtype, device=device)[..., :C].permute(0, 3, 1, 2), ld
 
 
+def aligned_view(x):
+    """nhwc_view + 16-byte-aligned pixels: a tensor whose pixel stride is not a multiple of 8 elements (1- or 2-channel
+    maps coming from outside the conv stack, e.g. the loss gradients) is copied once into a padded buffer, so that the
+    conv kernels read it with 16-byte vectors instead of element by element."""
+    xv, ld = nhwc_view(x)
+    if ld % 8 == 0:
+        return xv, ld
+    B, C, H, W = xv.shape
+    y, ldy = alloc_nhwc(B, C, H, W, xv.dtype, xv.device)
+    call("sdhip_affine_act", ptr(xv), ld, ptr(y), ldy, None, 0, None, None, B * H * W, C, 1, 0, dtype_code(xv), stream_ptr())
+    return y, ldy
+
+
 class _CorrFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, in1, in2, PH, PW, dil):
@@ -453,7 +466,7 @@ class _ConvFn(torch.autograd.Function):
         _require_gpu(x, weight)
         Bimg, Cin, H, W = x.shape
         B = Bimg // spec.D
-        xv, ldx = nhwc_view(x)
+        xv, ldx = aligned_view(x)
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
         wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
         y, ldy = alloc_nhwc(B * spec.Do, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
@@ -470,7 +483,7 @@ class _ConvFn(torch.autograd.Function):
         spec, act = ctx.spec, ctx.act
         B = xv.shape[0] // spec.D * spec.Do      # output images
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
-        g, ldg = nhwc_view(gy)
+        g, ldg = aligned_view(gy)
         if act:   # activation fused in the epilogue: derivative from the stored output
             g2, ldg2 = alloc_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
             call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(ysaved), nhwc_view(ysaved)[1], ptr(g2), ldg2, None, None, None, None, 1,
@@ -492,7 +505,7 @@ class _ConvBNActFn(torch.autograd.Function):
         Bimg, Cin, H, W = x.shape
         Btrue = Bimg // spec.D
         B = Btrue * spec.Do                      # output images
-        xv, ldx = nhwc_view(x)
+        xv, ldx = aligned_view(x)
         Cout = weight.shape[0] if spec.kind == 'conv' else weight.shape[1]
         wp = packed_weight(weight, spec.kind, 'fwd', x.dtype)
         yraw, ldr_ = alloc_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)

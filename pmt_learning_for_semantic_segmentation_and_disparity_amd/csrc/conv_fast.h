@@ -420,7 +420,9 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
 
   T* const yb = (T*)p.y + (long)blockIdx.z * p.Ho * p.Wo * p.ldy;
-  const bool interior = oh0 + TH <= p.Ho && ow0 + TW <= p.Wo && n0 + BN <= p.Cout;   // wave-uniform
+  // (accumulating launches take the general path: its per-tile branches keep the old values' loads from being hoisted
+  //  together, which would cost ~100 VGPRs — a wave of occupancy — in every launch of this kernel)
+  const bool interior = oh0 + TH <= p.Ho && ow0 + TW <= p.Wo && n0 + BN <= p.Cout && !p.accumulate;   // wave-uniform
   if (interior) {
     T* const d0 = yb + ((long)(oh0 + pt0 / TWT) * p.Wo + ow0 + (pt0 % TWT) * 16 + l15) * p.ldy + n0 + 4 * lg;
 #pragma unroll
@@ -430,14 +432,6 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
 #pragma unroll
       for (int mi = 0; mi < NT_CO; ++mi) {
         f32x4 v = acc[mi][ni];
-        if (p.accumulate) {   // uniform: gradient accumulation into a slab (DenseNet block backward)
-          if constexpr (sizeof(T) == 4) {
-            v += *reinterpret_cast<const f32x4*>(dst + mi * 16);
-          } else {
-            const u32x2 old = *reinterpret_cast<const u32x2*>(dst + mi * 16);
-            v += f32x4{bflo(old[0]), bfhi(old[0]), bflo(old[1]), bfhi(old[1])};
-          }
-        }
         if constexpr (sizeof(T) == 4) {
           *reinterpret_cast<f32x4*>(dst + mi * 16) = v;
         } else {

@@ -16,6 +16,7 @@
 // sweeps a strided share of all pixel tiles, and flushes once with f32 atomics
 // into the packed f32 gradient buffer.
 #include "conv_common.h"
+#include "conv_wgrad_fast.h"
 
 namespace {
 
@@ -388,6 +389,21 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
   if (!prezeroed) {
     if (hipMemsetAsync(dw_packed, 0, n * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
     if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
+  }
+  // ---- bf16 fast path (conv_wgrad_fast.h): 16-byte-aligned pixels on both operands ----
+  if (dtype == SDHIP_BF16 && a.vec_x && a.vec_dy && (long)H * W * ldx < (1L << 31) && (long)Ho * Wo * lddy < (1L << 31) &&
+      !getenv("SDHIP_WGRAD_GENERIC")) {
+    WgfArgs f;
+    f.x = x; f.dy = dy; f.dwp = dw_packed; f.dbias = dbias; f.in_scale = in_scale; f.in_shift = in_shift;
+    f.B = B; f.H = H; f.W = W; f.Ho = Ho; f.Wo = Wo; f.kh = kh; f.kw = kw; f.stride = stride; f.dil = dil; f.pad_t = pad_t; f.pad_l = pad_l;
+    f.D = D; f.Do = Do; f.kd = kd; f.sd = sd; f.pad_d = pad_d;
+    f.Cin = Cin; f.ldx = ldx; f.Cout = Cout; f.Mpad = a.Mpad; f.lddy = lddy;
+    f.in_relu = in_relu; f.bpg = B / groups;
+    f.tpb = a.tpb; f.ntg = a.ntg; f.nq = a.nq;
+    if (T == 1 && a.tpb == 1) { f.tpb = 1; f.ntg = 1; }
+    // MB = 32 regroups the taps over two wave groups: the tap grouping must match the instantiation (see launch_wgf_taps)
+    const int rc = in_scale ? launch_wgf_taps<false>(f, T, s) : launch_wgf_taps<true>(f, T, s);
+    if (rc != 1) return rc;   // 1: no tile fits LDS -> general kernel below
   }
   const bool wide = Wo >= 24;
   // bf16, 25 taps: 25 x (64 x 64) partial sums do not fit 8 waves' registers -> 32 output channels per workgroup

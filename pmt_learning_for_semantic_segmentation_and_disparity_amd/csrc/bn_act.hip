@@ -88,46 +88,63 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* gy, int ld
   }
   const long base = (long)g * npix_g;
   if (live) {
-    for (long pix = (long)blockIdx.x * rg.ty + ty; pix < npix_g; pix += (long)gridDim.x * rg.ty) {
-      float gv[N], xv[N];
-      Unit<T, VEC>::load(gy + (base + pix) * ldg + c0, gv);
-      Unit<T, VEC>::load(x + (base + pix) * ldx + c0, xv);
+    // 4 pixels per trip, all 8 loads issued before the first use: with the grid kept small for the sake of the
+    // atomics below (see there) each thread has to keep more bytes in flight itself
+    const long stride = (long)gridDim.x * rg.ty;
+    for (long pix0 = (long)blockIdx.x * rg.ty + ty; pix0 < npix_g; pix0 += 4 * stride) {
+      float gv[4][N], xv[4][N];
 #pragma unroll
-      for (int e = 0; e < N; ++e) {
-        const float z = fmaf(xv[e], sc[e], sf[e]);
-        float gm = gv[e];
-        if (act == 1) gm = z > 0.f ? gm : 0.f;
-        else if (act == 2) { const float sg = 1.f / (1.f + __expf(-z)); gm *= sg * (1.f - sg); }
-        else if (act == 4) gm *= z * (1.f - z);  // x holds the sigmoid OUTPUT
-        a1[e] = fmaf(gm, xv[e], a1[e]);
-        a2[e] += gm;
-        gv[e] = gm * sc[e];
-      }
-      if (gx) {
-        if (accumulate) {
-          float old[N];
-          Unit<T, VEC>::load(gx + (base + pix) * ldgx + c0, old);
-#pragma unroll
-          for (int e = 0; e < N; ++e) gv[e] += old[e];
+      for (int k = 0; k < 4; ++k) {
+        const long pix = pix0 + k * stride;
+        if (pix < npix_g) {
+          Unit<T, VEC>::load(gy + (base + pix) * ldg + c0, gv[k]);
+          Unit<T, VEC>::load(x + (base + pix) * ldx + c0, xv[k]);
         }
-        Unit<T, VEC>::store(gx + (base + pix) * ldgx + c0, gv);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long pix = pix0 + k * stride;
+        if (pix < npix_g) {
+#pragma unroll
+          for (int e = 0; e < N; ++e) {
+            const float z = fmaf(xv[k][e], sc[e], sf[e]);
+            float gm = gv[k][e];
+            if (act == 1) gm = z > 0.f ? gm : 0.f;
+            else if (act == 2) { const float sg = 1.f / (1.f + __expf(-z)); gm *= sg * (1.f - sg); }
+            else if (act == 4) gm *= z * (1.f - z);  // x holds the sigmoid OUTPUT
+            a1[e] = fmaf(gm, xv[k][e], a1[e]);
+            a2[e] += gm;
+            gv[k][e] = gm * sc[e];
+          }
+          if (gx) {
+            if (accumulate) {
+              float old[N];
+              Unit<T, VEC>::load(gx + (base + pix) * ldgx + c0, old);
+#pragma unroll
+              for (int e = 0; e < N; ++e) gv[k][e] += old[e];
+            }
+            Unit<T, VEC>::store(gx + (base + pix) * ldgx + c0, gv[k]);
+          }
+        }
       }
     }
   }
   if (!dscale) return;  // uniform
-  // reduce over the ty rows of the block, then one atomic per channel
+  // Reduce over the ty rows of the block in LDS, then ONE atomic wave-instruction per sum with consecutive lanes on
+  // consecutive channels.  Float atomics execute at the memory side, one 256-byte request at a time per line: thousands
+  // of workgroups x 16 scattered 8-lane instructions into the same replica line serialised into most of this kernel's
+  // run time (69 us on a 400 MB pass that streams in 25).
 #pragma unroll
   for (int e = 0; e < N; ++e) { red[0][threadIdx.x * N + e] = a1[e]; red[1][threadIdx.x * N + e] = a2[e]; }
   __syncthreads();
-  if (ty == 0 && u < rg.units) {
-#pragma unroll
-    for (int e = 0; e < N; ++e) {
-      float s1 = 0.f, s2 = 0.f;
-      for (int r = 0; r < rg.ty; ++r) { s1 += red[0][(r * rg.tx + tx) * N + e]; s2 += red[1][(r * rg.tx + tx) * N + e]; }
-      const long rep = (long)(blockIdx.x % nrep) * gridDim.z * C;   // replica r of [nrep][G][C]
-      atomicAdd(dscale + rep + g * C + c0 + e, s1);
-      atomicAdd(dshift + rep + g * C + c0 + e, s2);
-    }
+  const int nch = min(rg.tx, rg.units - blockIdx.y * rg.tx) * N;   // channels of this block's unit group
+  for (int cc = threadIdx.x; cc < 2 * nch; cc += 256) {
+    const int which = cc >= nch, ch = cc - which * nch;
+    const int txx = ch / N, e = ch - txx * N;
+    float sum = 0.f;
+    for (int r = 0; r < rg.ty; ++r) sum += red[which][(r * rg.tx + txx) * N + e];
+    const long rep = (long)(blockIdx.x % nrep) * gridDim.z * C;   // replica r of [nrep][G][C]
+    atomicAdd((which ? dshift : dscale) + rep + g * C + blockIdx.y * rg.tx * N + ch, sum);
   }
 }
 
@@ -180,15 +197,14 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
 #pragma unroll
   for (int e = 0; e < N; ++e) { red[0][threadIdx.x * N + e] = a1[e]; red[1][threadIdx.x * N + e] = a2[e]; }
   __syncthreads();
-  if (ty == 0 && u < rg.units) {
-#pragma unroll
-    for (int e = 0; e < N; ++e) {
-      double s1 = 0., s2 = 0.;
-      for (int r = 0; r < rg.ty; ++r) { s1 += red[0][(r * rg.tx + tx) * N + e]; s2 += red[1][(r * rg.tx + tx) * N + e]; }
-      double* Sr = S + (long)(blockIdx.x % nrep) * gridDim.z * 2 * ldc;   // replica r of [nrep][G][2][ldc]
-      atomicAdd(Sr + ((long)g * 2 + 0) * ldc + c0 + e, s1);
-      atomicAdd(Sr + ((long)g * 2 + 1) * ldc + c0 + e, s2);
-    }
+  const int nch = min(rg.tx, rg.units - blockIdx.y * rg.tx) * N;   // channels of this block's unit group
+  for (int cc = threadIdx.x; cc < 2 * nch; cc += 256) {             // consecutive lanes -> consecutive channels (see affine_act_bwd)
+    const int which = cc >= nch, ch = cc - which * nch;
+    const int txx = ch / N, e = ch - txx * N;
+    double sum = 0.;
+    for (int r = 0; r < rg.ty; ++r) sum += red[which][(r * rg.tx + txx) * N + e];
+    double* Sr = S + (long)(blockIdx.x % nrep) * gridDim.z * 2 * ldc;   // replica r of [nrep][G][2][ldc]
+    atomicAdd(Sr + ((long)g * 2 + which) * ldc + blockIdx.y * rg.tx * N + ch, sum);
   }
 }
 
@@ -299,12 +315,12 @@ bool vec_rows(int C, std::initializer_list<int> lds, std::initializer_list<const
 }
 
 struct Plan { RowGeom rg; dim3 grid; };
-Plan plan(int units, long npix_g, int G) {
+Plan plan(int units, long npix_g, int G, int max_blocks = 2048) {
   Plan p;
   p.rg = row_geom(units);
   const int gy = sdhip_cdiv(units, p.rg.tx);
   long gx = (npix_g + p.rg.ty - 1) / p.rg.ty;
-  const long cap = 2048 / ((long)gy * G) > 0 ? 2048 / ((long)gy * G) : 1;
+  const long cap = max_blocks / ((long)gy * G) > 0 ? max_blocks / ((long)gy * G) : 1;
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   p.grid = dim3((unsigned)gx, (unsigned)gy, (unsigned)G);
@@ -381,12 +397,12 @@ extern "C" int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int 
 #define ARGS(T) (const T*)gy, ldg, (const T*)x, ldx, (T*)gx, ldgx, scale, shift, dscale, dshift, nrep, C, npix / G, act, accumulate
   if (dtype == SDHIP_F32) {
     const bool v = vec_rows<float>(C, {ldg, ldx, gx ? ldgx : 0}, {gy, x, gx});
-    Plan pl = plan(v ? C / 4 : C, npix / G, G);
+    Plan pl = plan(v ? C / 4 : C, npix / G, G, 1024);
     if (v) hipLaunchKernelGGL((affine_act_bwd_kernel<float, true>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
     else hipLaunchKernelGGL((affine_act_bwd_kernel<float, false>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
   } else {
     const bool v = vec_rows<bf16_t>(C, {ldg, ldx, gx ? ldgx : 0}, {gy, x, gx});
-    Plan pl = plan(v ? C / 8 : C, npix / G, G);
+    Plan pl = plan(v ? C / 8 : C, npix / G, G, 1024);
     if (v) hipLaunchKernelGGL((affine_act_bwd_kernel<bf16_t, true>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
     else hipLaunchKernelGGL((affine_act_bwd_kernel<bf16_t, false>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
   }
@@ -434,12 +450,12 @@ extern "C" int sdhip_channel_stats(const void* x, int ldx, double* stats, int ld
 #define ARGS(T) (const T*)x, ldx, stats, ldc, nrep, C, npix / G
   if (dtype == SDHIP_F32) {
     const bool v = vec_rows<float>(C, {ldx}, {x});
-    Plan pl = plan(v ? C / 4 : C, npix / G, G);
+    Plan pl = plan(v ? C / 4 : C, npix / G, G, 1024);
     if (v) hipLaunchKernelGGL((channel_stats_kernel<float, true>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
     else hipLaunchKernelGGL((channel_stats_kernel<float, false>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
   } else {
     const bool v = vec_rows<bf16_t>(C, {ldx}, {x});
-    Plan pl = plan(v ? C / 8 : C, npix / G, G);
+    Plan pl = plan(v ? C / 8 : C, npix / G, G, 1024);
     if (v) hipLaunchKernelGGL((channel_stats_kernel<bf16_t, true>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
     else hipLaunchKernelGGL((channel_stats_kernel<bf16_t, false>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
   }

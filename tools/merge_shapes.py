@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[2])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def dur(r): return (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 fw = [r for r in rows if "conv_fwd_kernel" in r["Kernel_Name"] or "conv_fast_kernel" in r["Kernel_Name"]]
-wg = [r for r in rows if "conv_wgrad_kernel" in r["Kernel_Name"]]
+wg = [r for r in rows if "conv_wgrad_kernel" in r["Kernel_Name"] or "wgrad_fast_kernel" in r["Kernel_Name"]]
 nf = sum(1 for d in log if d["k"] == "fwd"); nw = len(log) - nf
 fw, wg = fw[-nf:], wg[-nw:]
 agg = collections.OrderedDict()

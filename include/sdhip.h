@@ -129,6 +129,11 @@ int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* d
 /* Pack many weights in one launch: desc = ndesc rows of 8 int64 {src ptr, dst ptr, M, K, T, stride_m, stride_k, flip}
  * in device memory (same layout rules as sdhip_conv_pack_weights). */
 int sdhip_conv_pack_batch(const long* desc, int ndesc, int dtype, void* stream);
+/* One launch unpacks (adds) every weight gradient of the step into the flat gradient buffer:
+ * desc[i] = {acc ptr (f32, packed as written by sdhip_conv2d_wgrad), grad ptr, M, K, T, stride_m, stride_k, flip};
+ * grad(m,k,t) += acc[k/CK][flip ? T-1-t : t][m][k%CK].  Replaces ~200 per-layer sdhip_conv_unpack_wgrad launches of a
+ * training step (the optimizer reads the gradients only after the whole backward pass: util/torch_implementation.py:389,724). */
+int sdhip_conv_unpack_batch(const long* desc, int ndesc, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * BatchNorm2d in training mode (+ ReLU / sigmoid / skip add), decomposed so the

@@ -346,6 +346,33 @@ extern "C" int sdhip_conv_pack_batch(const long* desc, int ndesc, int dtype, voi
   return SDHIP_OK;
 }
 
+// desc[i] = {acc ptr, grad ptr, M, K, T, stride_m, stride_k, flip}: grad(m,k,t) += acc[k/CK][tt][m][k%CK]
+__global__ void unpack_batch_kernel(const long* __restrict__ desc, int CK) {
+  const long* d = desc + (long)blockIdx.y * 8;
+  const float* acc = reinterpret_cast<const float*>(d[0]);
+  float* grad = reinterpret_cast<float*>(d[1]);
+  const int M = (int)d[2], K = (int)d[3], Tn = (int)d[4], flip = (int)d[7];
+  const long sm = d[5], sk = d[6];
+  const int Mpad = (M + 15) & ~15;
+  const long total = (long)M * K * Tn;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % Tn);
+    long r = i / Tn;
+    const int k = (int)(r % K);
+    const int m = (int)(r / K);
+    const int tt = flip ? Tn - 1 - t : t;
+    grad[m * sm + k * sk + t] += acc[(((long)(k / CK) * Tn + tt) * Mpad + m) * CK + (k % CK)];
+  }
+}
+
+extern "C" int sdhip_conv_unpack_batch(const long* desc, int ndesc, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(desc && ndesc > 0, "conv_unpack_batch: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv_unpack_batch: unknown dtype %d", dtype);
+  hipLaunchKernelGGL(unpack_batch_kernel, dim3(16, ndesc), dim3(256), 0, (hipStream_t)stream, desc, conv_ck(dtype));
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
 extern "C" int sdhip_conv_unpack_wgrad(const float* acc, float* grad, int M, int K, int T,
                                        long stride_m, long stride_k, int flip, int accumulate, int dtype, void* stream) {
   SDHIP_CHECK_ARG(acc && grad && M > 0 && K > 0 && T > 0, "conv_unpack_wgrad: bad arguments");

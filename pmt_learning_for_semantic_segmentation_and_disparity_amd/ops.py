@@ -126,14 +126,28 @@ class StepContext:
         self.nbt = None          # list of (tensor, increment) recorded while measuring
         self.side = None         # second HIP stream: weight gradients run beside the data-gradient chain
         self.keep = []           # tensors the side stream still reads (kept alive until join())
+        self.unpacks = []        # deferred weight-gradient unpack descriptors of the running step (direct_grads)
+        self.unpack_key = None   # the descriptor rows the cached device table was built from
+        self.unpack_desc = None
 
     def join(self):
-        """Main stream waits for the side stream (call after backward, before the optimizer)."""
+        """Main stream waits for the side stream (call after backward, before the optimizer), then ONE launch adds every
+        packed weight-gradient accumulator of the step into the flat gradient buffer."""
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+        if self.unpacks:
+            key = tuple(self.unpacks)
+            if key != self.unpack_key:   # arena offsets and gradient slices repeat step after step: built once
+                if torch.cuda.is_current_stream_capturing():
+                    raise _lib.SdhipError("weight-gradient layout changed between the warm-up step and graph capture")
+                self.unpack_desc = torch.tensor(self.unpacks, dtype=torch.int64, device=self.device)
+                self.unpack_key = key
+            call("sdhip_conv_unpack_batch", ptr(self.unpack_desc), len(self.unpacks), self.unpack_dt, stream_ptr())
+            self.unpacks = []
         self.keep.clear()
 
     def begin_step(self):
+        self.unpacks = []
         if self.arena is not None:
             self.offset = 0
             self.arena.zero_()
@@ -452,9 +466,15 @@ def _wgrad_impl(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu
     target = tw
     if target is None:
         gw = target = torch.empty_like(weight, memory_format=torch.contiguous_format)
+    c = _ctx[0]
+    defer = c is not None and c.direct_grads and tw is not None and pz and c.arena is not None
     for src_off, blk, M, K, T_, sm, sk, flip in _pack_rows(weight, spec.kind, 'fwd', dt):
-        call("sdhip_conv_unpack_wgrad", ctypes_ptr(acc.data_ptr() + 4 * per * blk), ctypes_ptr(target.data_ptr() + 4 * src_off),
-             M, K, T_, sm, sk, flip, 1 if tw is not None else 0, dt, stream_ptr())
+        if defer:   # accumulators live in the step's zero arena until join(): unpack all of them in one launch there
+            c.unpacks.append((acc.data_ptr() + 4 * per * blk, target.data_ptr() + 4 * src_off, M, K, T_, sm, sk, flip))
+            c.unpack_dt = dt
+        else:
+            call("sdhip_conv_unpack_wgrad", ctypes_ptr(acc.data_ptr() + 4 * per * blk), ctypes_ptr(target.data_ptr() + 4 * src_off),
+                 M, K, T_, sm, sk, flip, 1 if tw is not None else 0, dt, stream_ptr())
     return gw, gb
 
 

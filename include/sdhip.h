@@ -258,6 +258,27 @@ int sdhip_log_softmax_fwd(const void* x, int ldx, void* y, int ldy, long npix, i
 int sdhip_log_softmax_bwd(const void* gy, int ldg, const void* y, int ldy, void* gx, int ldgx, long npix, int C,
                           int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Height-driven attention (HANet_Conv.forward, models_hanet/HANet.py:74-128) — the data-sized pieces; the tiny
+ * (B, C, L) convolutions / BatchNorm1d / sigmoid / resize in between run through the conv / BN / resize entry points
+ * on (B, C, L, 1) images.
+ * rowpool_max: nn.AdaptiveMaxPool2d((OH, 1)) (HANet.py:50-55,84): y[b,i,c] = max over rows [floor(i*H/OH),
+ *   ceil((i+1)*H/OH)) and all columns of x[b,:,:,c]; idx[b,i,c] = h*W+w of the first maximum (int32, dense [B][OH][C]).
+ * mul_rows: torch.mul(out, attention.unsqueeze(3)) (HANet.py:112): y[b,h,w,c] = a[b,h,w,c] * att[b,h,c].
+ * dropout_channels: nn.Dropout2d(p) on a (B, C, L) tensor (HANet.py:27-28,90-91): whole (b,c) rows dropped, rest scaled by
+ *   1/(1-p); mask from a counter hash of (*seed, layer_id, b*C+c) — the same call on the gradient is the backward.
+ * ------------------------------------------------------------------------- */
+int sdhip_rowpool_max_fwd(const void* x, int ldx, void* y, int ldy, int* idx, int B, int H, int W, int C, int OH,
+                          int dtype, void* stream);
+int sdhip_rowpool_max_bwd(const void* gy, int ldg, const int* idx, void* gx, int ldgx, int B, int H, int W, int C, int OH,
+                          int dtype, void* stream);
+int sdhip_mul_rows_fwd(const void* a, int lda, const void* att, int ldt, void* y, int ldy, int B, int H, int W, int C,
+                       int dtype, void* stream);
+int sdhip_mul_rows_bwd(const void* g, int ldg, const void* a, int lda, const void* att, int ldt, void* ga, int ldga,
+                       void* gatt, int ldgt, int B, int H, int W, int C, int dtype, void* stream);
+int sdhip_dropout_channels(const void* x, int ldx, void* y, int ldy, const long* seed, long layer_id, int B, int L, int C,
+                           float p, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

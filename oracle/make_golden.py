@@ -212,6 +212,68 @@ def gen_nets():
     save("nets", **arrays)
 
 
+def _pos(B, H, W):
+    """The position maps of util/torch_implementation.py:139-143 at a reduced size (row index // 8 semantics kept:
+    values 0..127 over the image height)."""
+    h = (torch.arange(0, H) * 1024 // H).unsqueeze(0).unsqueeze(2).expand(B, -1, W) // 8
+    w = (torch.arange(0, W) * 2048 // W).unsqueeze(0).unsqueeze(1).expand(B, H, -1) // 16
+    return h, w
+
+
+def gen_hanet():
+    """HANet head alone (train: batch-statistics BatchNorm1d, dropout off; eval) and inside minidsnetExt (eval)."""
+    torch.Tensor.cuda = lambda self, *a, **k: self      # PosEncoding1D hard-codes .cuda() (models_hanet/PosEmbedding.py:54,68)
+    from models_hanet.HANet import HANet_Conv
+    from models import dsnet_t2 as D
+    arrays = {}
+    for mode in ("train", "eval"):
+        ref = fill_state_dict(HANet_Conv(64, 5, pooling='max', pos_rfactor=2, dropout_prob=0.0 if mode == "train" else 0.1), 41)
+        ref.train() if mode == "train" else ref.eval()
+        x = randn_input(41, "hx", (2, 64, 128, 24)).requires_grad_(True)
+        out = randn_input(41, "hout", (2, 5, 96, 40)).requires_grad_(True)
+        pos = _pos(2, 256, 8)
+        y, logits = ref(x, out, pos, attention_loss=True)
+        gy = randn_input(42, "hgy", tuple(y.shape))
+        (y * gy).sum().backward()
+        p = "hanet.%s" % mode
+        arrays.update(flat(p + ".y", sample(y, 4)))
+        arrays[p + ".logits"] = logits.detach().numpy().copy()
+        arrays[p + ".gx.norm"] = np.float64(x.grad.norm().item())
+        arrays.update(flat(p + ".gx", sample(x.grad, 4)))
+        arrays.update(flat(p + ".gout", sample(out.grad, 4)))
+        for k, v in ref.named_parameters():
+            if v.grad is not None:
+                arrays["%s.gw.%s" % (p, k)] = v.grad.numpy().copy()
+        if mode == "train":
+            arrays[p + ".rm2"] = ref.attention_second[1].running_mean.numpy().copy()
+            arrays[p + ".rv2"] = ref.attention_second[1].running_var.numpy().copy()
+        mine = R.HANet_Conv(64, 5, pooling='max', pos_rfactor=2, dropout_prob=0.0 if mode == "train" else 0.1)
+        mine.load_state_dict(fill_state_dict(HANet_Conv(64, 5, pooling='max', pos_rfactor=2, dropout_prob=0.0), 41).state_dict())
+        mine.train() if mode == "train" else mine.eval()
+        my, ml = mine(x.detach(), out.detach(), pos, attention_loss=True)
+        assert float((my - y).abs().max()) < 1e-5 and float((ml - logits).abs().max()) < 1e-5, mode
+        print("hanet", mode, "oracle==reference")
+    # inside the network (eval: Dropout2d(0.1) inactive)
+    cfg = R.CFG(aspp=0, hanet=1)
+    ref = fill_state_dict(D.minidsnetExt(cfg, labels=2, pretrained=False, patch_type='1dcorr', backbone='densenet'), 43).eval()
+    a, b = rand_input(43, "left", (2, 3, 256, 256)), rand_input(43, "right", (2, 3, 256, 256))
+    pos = _pos(2, 256, 256)
+    with torch.no_grad():
+        outs = ref(a, b, pos)
+    for i, name in enumerate(("seg1", "disp", "seg2")):
+        arrays.update(flat("mini_hanet.eval.%s" % name, sample(outs[i], 8)))
+    mine = R.minidsnetExt(cfg, labels=2, patch_type='1dcorr')
+    mine.load_state_dict(ref.state_dict())
+    mine.eval()
+    with torch.no_grad():
+        mo = mine(a, b, pos)
+    for x_, y_ in zip(mo, outs):
+        assert float((x_ - y_).abs().max()) < 2e-4
+    print("mini_hanet eval oracle==reference")
+    arrays["meta.corr"] = np.array("assumed-semantics")
+    save("hanet", **arrays)
+
+
 def gen_dsnet():
     from models import dsnet_t2 as D
     arrays = {}
@@ -277,7 +339,7 @@ if __name__ == "__main__":
     _install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet"]
+    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet", "hanet"]
     if "ops" in which:
         gen_ops()
     if "backbone" in which:
@@ -288,3 +350,5 @@ if __name__ == "__main__":
         gen_psmnet()
     if "dsnet" in which:
         gen_dsnet()
+    if "hanet" in which:
+        gen_hanet()

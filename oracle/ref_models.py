@@ -379,12 +379,95 @@ class CFG:
         self.hanet, self.convDeconvOut, self.abilation = hanet, convDeconvOut, abilation
 
 
+# --------------------------------------------------------------------------- HANet (models_hanet/*)
+def get_sinusoid_encoding_table(n_position, d_hid):
+    """models_hanet/PosEmbedding.py:7-28 (the reference's last assignment wins: cycle = 10 if d_hid > 50 else 100)."""
+    import numpy as np
+    cycle = 10 if d_hid > 50 else 100
+    table = np.array([[pos / np.power(cycle, 2 * (j // 2) / d_hid) for j in range(d_hid)] for pos in range(n_position)])
+    table[:, 0::2] = np.sin(table[:, 0::2])
+    table[:, 1::2] = np.cos(table[:, 1::2])
+    return torch.FloatTensor(table)
+
+
+class PosEncoding1D(nn.Module):
+    """models_hanet/PosEmbedding.py:49-85 without the hard-coded .cuda() calls (pos_noise = 0)."""
+
+    def __init__(self, pos_rfactor, dim, pos_noise=0.0):
+        super().__init__()
+        assert pos_noise == 0.0
+        self.pos_layer = nn.Embedding.from_pretrained(get_sinusoid_encoding_table((128 // pos_rfactor) + 1, dim) + 1, freeze=True)
+        self.pos_rfactor = pos_rfactor
+
+    def forward(self, x, pos):
+        pos_h, _ = pos
+        pos_h = pos_h // self.pos_rfactor
+        pos_h = pos_h.index_select(2, torch.tensor([0])).unsqueeze(1).squeeze(3)
+        pos_h = F.interpolate(pos_h.float(), size=x.shape[2], mode='nearest').long()
+        return x + self.pos_layer(pos_h).transpose(1, 3).squeeze(3)
+
+
+class HANet_Conv(nn.Module):
+    """models_hanet/HANet.py:9-128 (pooling 'max' | 'mean', sinusoid encoding, the attention_loss return form)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size=3, r_factor=64, layer=3, pos_injection=2, is_encoding=1,
+                 pos_rfactor=8, pooling='mean', dropout_prob=0.0, pos_noise=0.0):
+        super().__init__()
+        import math
+        assert is_encoding == 1
+        self.pooling, self.pos_injection, self.layer, self.dropout_prob = pooling, pos_injection, layer, dropout_prob
+        self.sigmoid = nn.Sigmoid()
+        mid_1 = math.ceil(in_channel / r_factor) if r_factor > 0 else in_channel * (-r_factor)
+        if dropout_prob > 0:
+            self.dropout = nn.Dropout2d(dropout_prob)
+        self.attention_first = nn.Sequential(nn.Conv1d(in_channel, mid_1, 1, bias=False), nn.BatchNorm1d(mid_1), nn.ReLU(inplace=True))
+        if layer == 2:
+            self.attention_second = nn.Sequential(nn.Conv1d(mid_1, out_channel, kernel_size, padding=kernel_size // 2, bias=True))
+        else:
+            mid_2 = mid_1 * 2
+            self.attention_second = nn.Sequential(nn.Conv1d(mid_1, mid_2, 3, padding=1, bias=True), nn.BatchNorm1d(mid_2),
+                                                  nn.ReLU(inplace=True))
+            self.attention_third = nn.Sequential(nn.Conv1d(mid_2, out_channel, kernel_size, padding=kernel_size // 2, bias=True))
+        rows = 128 // pos_rfactor
+        self.rowpool = nn.AdaptiveAvgPool2d((rows, 1)) if pooling == 'mean' else nn.AdaptiveMaxPool2d((rows, 1))
+        if pos_rfactor > 0:
+            if pos_injection == 1:
+                self.pos_emb1d_1st = PosEncoding1D(pos_rfactor, dim=in_channel, pos_noise=pos_noise)
+            else:
+                self.pos_emb1d_2nd = PosEncoding1D(pos_rfactor, dim=mid_1, pos_noise=pos_noise)
+
+    def forward(self, x, out, pos=None, return_attention=False, return_posmap=False, attention_loss=False):
+        H = out.size(2)
+        x1d = self.rowpool(x).squeeze(3)
+        if pos is not None and self.pos_injection == 1:
+            x1d = self.pos_emb1d_1st(x1d, pos)
+        if self.dropout_prob > 0:
+            x1d = self.dropout(x1d)
+        x1d = self.attention_first(x1d)
+        if pos is not None and self.pos_injection == 2:
+            x1d = self.pos_emb1d_2nd(x1d, pos)
+        x1d = self.attention_second(x1d)
+        if self.layer == 3:
+            x1d = self.attention_third(x1d)
+        last_attention = x1d
+        x1d = self.sigmoid(x1d)
+        x1d = F.interpolate(x1d, size=H, mode='linear')
+        out = torch.mul(out, x1d.unsqueeze(3))
+        if return_attention:
+            return out, x1d
+        if attention_loss:
+            return out, last_attention
+        return out
+
+
 class minidsnetExt(nn.Module):
-    """models/dsnet_t2.py:941-1299 — densenet backbone, no multitask loss, no HANet."""
+    """models/dsnet_t2.py:941-1299 — densenet backbone, no multitask loss; HANet head as upstream (built when
+    CFG.hanet, applied only on the non-aspp-2 branch: dsnet_t2.py:1135-1150,1287-1289)."""
 
     def __init__(self, CFG, labels=8, pretrained=False, patch_type='', include_edges=False, backbone='densenet'):
         super().__init__()
-        assert backbone == 'densenet' and not CFG.multaskloss and not CFG.hanet and not include_edges
+        assert backbone == 'densenet' and not CFG.multaskloss and not include_edges
+        self.hanet = CFG.hanet
         dropout = CFG.dropout
         self.aspp_mod, self.use_att, self.convDeconvOut, self.abilation = CFG.aspp, CFG.use_att, CFG.convDeconvOut, CFG.abilation
         self.patch_type, self.backbone = patch_type, backbone
@@ -425,6 +508,16 @@ class minidsnetExt(nn.Module):
         else:
             self.Conv2DownUp11 = nn.Sequential(Conv2DownUp(32, 32, 3, lastLayer=False, dropout=dropout),
                                                ConvTranspose2dSame(32, labels, 3, 1, padding='same', init_he=False))
+        if self.hanet:
+            self.hanet_last = HANet_Conv(64, labels, pooling='max', pos_rfactor=2, dropout_prob=0.1)
+            for m in self.hanet_last.modules():
+                if isinstance(m, nn.Conv1d):
+                    nn.init.kaiming_normal_(m.weight, nonlinearity='relu')
+                    if m.bias is not None:
+                        m.bias.data.zero_()
+                elif isinstance(m, nn.BatchNorm1d):
+                    m.weight.data.fill_(1)
+                    m.bias.data.zero_()
 
     def forward(self, input_a, input_b, pos=None, disp_gt=None, seg_gt=None):
         a = self.resnet_features(input_a)  # a_0..a_4, B2, B1, B0
@@ -478,6 +571,8 @@ class minidsnetExt(nn.Module):
             if self.convDeconvOut:
                 s = self.convOutput2(seg2)
                 seg2 = (self.convOutput(seg2) + s) if self.convDeconvOut == 2 else s
+            if self.hanet:
+                seg2, _ = self.hanet_last(a[0], seg2, pos, attention_loss=True)
         return seg1, disp, seg2, disp
 
 

@@ -43,6 +43,11 @@ SIGNATURES = {
     "sdhip_conv2d_wgrad": [_p, _p, _p, _p, _p, _p] + [_i] * 24 + [_p],
     "sdhip_conv_pack_batch": [_p, _i, _i, _p],
     "sdhip_conv_unpack_batch": [_p, _i, _i, _p],
+    "sdhip_rowpool_max_fwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_rowpool_max_bwd": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_mul_rows_fwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_mul_rows_bwd": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_dropout_channels": [_p, _i, _p, _i, _p, _l, _i, _i, _i, _f, _i, _p],
     "sdhip_channel_stats": [_p, _i, _p, _i, _i, _l, _i, _i, _i, _i, _p],
     "sdhip_stats_replica_sum": [_p, _p, _i, _i, _i, _i, _i, _p],
     "sdhip_bn_finalize": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _d, _f, _f, _p],

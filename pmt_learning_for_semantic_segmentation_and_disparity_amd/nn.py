@@ -252,8 +252,9 @@ class minidsnetExt(nn.Module):
 
     def __init__(self, CFG, labels=8, pretrained=False, patch_type='', include_edges=False, backbone='densenet'):
         super().__init__()
-        if backbone != 'densenet' or CFG.multaskloss or CFG.hanet or include_edges:
-            raise NotImplementedError("native path: densenet backbone, no multitask loss / HANet / edge channel yet")
+        if backbone != 'densenet' or CFG.multaskloss or include_edges:
+            raise NotImplementedError("native path: densenet backbone, no multitask loss / edge channel yet")
+        self.hanet = CFG.hanet
         dropout = CFG.dropout
         self.aspp_mod, self.use_att, self.convDeconvOut, self.abilation = CFG.aspp, CFG.use_att, CFG.convDeconvOut, CFG.abilation
         self.patch_type, self.backbone = patch_type, backbone
@@ -296,6 +297,17 @@ class minidsnetExt(nn.Module):
         else:
             self.Conv2DownUp11 = nn.Sequential(Conv2DownUp(32, 32, 3, lastLayer=False, dropout=dropout),
                                                ConvTranspose2dSame(32, labels, 3, 1, padding='same', init_he=False))
+        if self.hanet:   # models/dsnet_t2.py:1135-1150
+            from .hanet import HANet_Conv
+            self.hanet_last = HANet_Conv(64, labels, pooling='max', pos_rfactor=2, dropout_prob=0.1)
+            for m in self.hanet_last.modules():
+                if isinstance(m, nn.Conv1d):
+                    nn.init.kaiming_normal_(m.weight, nonlinearity='relu')
+                    if m.bias is not None:
+                        m.bias.data.zero_()
+                elif isinstance(m, nn.BatchNorm1d):
+                    m.weight.data.fill_(1)
+                    m.bias.data.zero_()
 
     def forward(self, input_a, input_b, pos=None, disp_gt=None, seg_gt=None):
         _no_dropout(self.conv1d_at_d[2].p, self.training)
@@ -369,6 +381,8 @@ class minidsnetExt(nn.Module):
                 seg2 = ops.affine_act(self.convOutput(seg2), None, None, s) if self.convDeconvOut == 2 else s
             else:
                 seg2 = self.Conv2DownUp11[1](seg2)
+            if self.hanet:   # only on this branch, as upstream (models/dsnet_t2.py:1287-1289): with aspp == 2 the head is built but unused
+                seg2, _ = self.hanet_last(a[0], seg2, pos, attention_loss=True)
         return seg1, disp, seg2, disp
 
 

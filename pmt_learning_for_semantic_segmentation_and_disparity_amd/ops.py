@@ -666,7 +666,7 @@ def conv_spec(x, weight, kind='conv', stride=1, dilation=1, padding=0):
             raise _lib.SdhipError("'same' padding needs a square kernel")
         Ho, Wo, pt, pl = conv_same_geometry(H, W, kh, stride, dilation)
     else:
-        pt = pl = int(padding)
+        pt, pl = (int(padding[0]), int(padding[1])) if isinstance(padding, (tuple, list)) else (int(padding), int(padding))
         Ho = (H + 2 * pt - dilation * (kh - 1) - 1) // stride + 1
         Wo = (W + 2 * pl - dilation * (kw - 1) - 1) // stride + 1
     return ConvSpec(kind, kh, kw, stride, dilation, pt, pl, Ho, Wo)
@@ -1010,6 +1010,101 @@ def dropout(x, p, training, layer_id):
     if not training or p == 0.0:
         return x
     return _DropoutFn.apply(x, float(p), int(layer_id))
+
+
+# ============================================================================ HANet pieces (models_hanet/HANet.py:74-128)
+class _RowPoolMaxFn(torch.autograd.Function):
+    """nn.AdaptiveMaxPool2d((OH, 1)): (B,C,H,W) -> (B,C,OH,1)."""
+
+    @staticmethod
+    def forward(ctx, x, OH):
+        _require_gpu(x)
+        B, C, H, W = x.shape
+        xv, ldx = nhwc_view(x)
+        y, ldy = alloc_nhwc(B, C, OH, 1, x.dtype, x.device)
+        idx = torch.empty((B, OH, C), dtype=torch.int32, device=x.device)
+        call("sdhip_rowpool_max_fwd", ptr(xv), ldx, ptr(y), ldy, ptr(idx), B, H, W, C, OH, dtype_code(x), stream_ptr())
+        ctx.save_for_backward(idx)
+        ctx.cfg = (B, C, H, W, OH)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        B, C, H, W, OH = ctx.cfg
+        g, ldg = nhwc_view(gy)
+        gx, ldgx = alloc_nhwc(B, C, H, W, gy.dtype, gy.device)
+        call("sdhip_rowpool_max_bwd", ptr(g), ldg, ptr(idx), ptr(gx), ldgx, B, H, W, C, OH, dtype_code(gy), stream_ptr())
+        return gx, None
+
+
+def rowpool_max(x, OH):
+    return _RowPoolMaxFn.apply(x, int(OH))
+
+
+class _MulRowsFn(torch.autograd.Function):
+    """a (B,C,H,W) * att (B,C,H,1): torch.mul(out, x1d.unsqueeze(3)) of models_hanet/HANet.py:112."""
+
+    @staticmethod
+    def forward(ctx, a, att):
+        _require_gpu(a, att)
+        B, C, H, W = a.shape
+        if tuple(att.shape) != (B, C, H, 1):
+            raise _lib.SdhipError("mul_rows: attention must be (B,C,H,1), got %s for %s" % (tuple(att.shape), tuple(a.shape)))
+        av, lda = nhwc_view(a)
+        tv, ldt = nhwc_view(att)
+        y, ldy = alloc_nhwc(B, C, H, W, a.dtype, a.device)
+        call("sdhip_mul_rows_fwd", ptr(av), lda, ptr(tv), ldt, ptr(y), ldy, B, H, W, C, dtype_code(a), stream_ptr())
+        ctx.save_for_backward(av, tv)
+        ctx.cfg = (lda, ldt)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        av, tv = ctx.saved_tensors
+        lda, ldt = ctx.cfg
+        B, C, H, W = av.shape
+        gv, ldg = nhwc_view(g)
+        ga, ldga = alloc_nhwc(B, C, H, W, av.dtype, av.device)
+        gt, ldgt = alloc_nhwc(B, C, H, 1, av.dtype, av.device)
+        call("sdhip_mul_rows_bwd", ptr(gv), ldg, ptr(av), lda, ptr(tv), ldt, ptr(ga), ldga, ptr(gt), ldgt, B, H, W, C,
+             dtype_code(av), stream_ptr())
+        return ga, gt
+
+
+def mul_rows(a, att):
+    return _MulRowsFn.apply(a, att)
+
+
+class _DropoutChannelsFn(torch.autograd.Function):
+    """nn.Dropout2d on a (B,C,L[,1]) row descriptor: whole (sample, channel) rows are dropped."""
+
+    @staticmethod
+    def forward(ctx, x, p, layer_id):
+        _require_gpu(x)
+        B, C, L, W = x.shape
+        xv, ldx = nhwc_view(x)
+        y, ldy = alloc_nhwc(B, C, L, W, x.dtype, x.device)
+        call("sdhip_dropout_channels", ptr(xv), ldx, ptr(y), ldy, ptr(rng_seed_tensor(x.device)), layer_id, B, L * W, C, p,
+             dtype_code(x), stream_ptr())
+        ctx.cfg = (p, layer_id)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        p, layer_id = ctx.cfg
+        B, C, L, W = gy.shape
+        g, ldg = nhwc_view(gy)
+        gx, ldgx = alloc_nhwc(B, C, L, W, gy.dtype, gy.device)
+        call("sdhip_dropout_channels", ptr(g), ldg, ptr(gx), ldgx, ptr(rng_seed_tensor(gy.device)), layer_id, B, L * W, C, p,
+             dtype_code(gy), stream_ptr())
+        return gx, None, None
+
+
+def dropout_channels(x, p, training, layer_id):
+    if not training or p == 0.0:
+        return x
+    return _DropoutChannelsFn.apply(x, float(p), int(layer_id))
 
 
 def global_avg_pool(x):

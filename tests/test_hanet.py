@@ -1,0 +1,125 @@
+"""HANet head: oracle vs reference-captured golden vectors (CPU); HIP path vs golden (GPU).
+Fixtures: oracle/make_golden.py gen_hanet (reference models_hanet/HANet.py imported in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_models as R
+from oracle.detweights import fill_state_dict, rand_input, randn_input
+from test_nets import _check
+
+GDIR = os.path.join(os.path.dirname(__file__), "golden")
+GOLD = os.path.join(GDIR, "hanet.npz")
+
+
+def _pos(B, H, W):
+    h = (torch.arange(0, H) * 1024 // H).unsqueeze(0).unsqueeze(2).expand(B, -1, W) // 8
+    w = (torch.arange(0, W) * 2048 // W).unsqueeze(0).unsqueeze(1).expand(B, H, -1) // 16
+    return h, w
+
+
+def _module_case(mode):
+    x = randn_input(41, "hx", (2, 64, 128, 24))
+    out = randn_input(41, "hout", (2, 5, 96, 40))
+    gy = randn_input(42, "hgy", (2, 5, 96, 40))
+    return x, out, gy, _pos(2, 256, 8), (0.0 if mode == "train" else 0.1)
+
+
+def _run_module(cls, mode, dev):
+    x, out, gy, pos, p = _module_case(mode)
+    m = fill_state_dict(cls(64, 5, pooling='max', pos_rfactor=2, dropout_prob=p), 41).to(dev)
+    m.train() if mode == "train" else m.eval()
+    x = x.to(dev).requires_grad_(True)
+    out = out.to(dev).requires_grad_(True)
+    y, logits = m(x, out, tuple(t.to(dev) for t in pos), attention_loss=True)
+    (y * gy.to(dev)).sum().backward()
+    return m, x, out, y, logits
+
+
+def _check_module(gold, mode, m, x, out, y, logits, tol):
+    p = "hanet.%s" % mode
+    _check(gold, p + ".y", y, tol, stride=4)
+    np.testing.assert_allclose(logits.detach().float().cpu().numpy().reshape(gold[p + ".logits"].shape), gold[p + ".logits"],
+                               rtol=tol, atol=tol)
+    _check(gold, p + ".gx", x.grad, tol, stride=4)
+    _check(gold, p + ".gout", out.grad, tol, stride=4)
+    assert abs(float(x.grad.norm()) - float(gold[p + ".gx.norm"])) <= tol * max(1.0, float(gold[p + ".gx.norm"]))
+    for k, v in m.named_parameters():
+        key = "%s.gw.%s" % (p, k)
+        if key in gold.files:
+            want = gold[key]
+            if v.grad is None:       # conv bias in front of a train-mode BatchNorm: exactly zero gradient upstream
+                assert np.abs(want).max() < 1e-5, key
+                continue
+            got = v.grad.detach().float().cpu().numpy().reshape(want.shape)
+            np.testing.assert_allclose(got, want, rtol=5 * tol, atol=5 * tol * max(1.0, float(np.abs(want).max())), err_msg=key)
+    if mode == "train":
+        np.testing.assert_allclose(m.attention_second[1].running_mean.cpu().numpy(), gold[p + ".rm2"], rtol=tol, atol=tol)
+        np.testing.assert_allclose(m.attention_second[1].running_var.cpu().numpy(), gold[p + ".rv2"], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_oracle_hanet_matches_golden(mode):
+    gold = np.load(GOLD)
+    _check_module(gold, mode, *_run_module(R.HANet_Conv, mode, "cpu"), 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_hip_hanet_matches_golden(mode):
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.hanet import HANet_Conv
+    gold = np.load(GOLD)
+    _check_module(gold, mode, *_run_module(HANet_Conv, mode, "cuda"), 1e-3)
+
+
+@pytest.mark.gpu
+def test_hip_hanet_ops_match_torch():
+    """row max-pool (values, argmax routing of the gradient) and row re-weighting vs ATen on the same tensors; uneven bins."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    x = randn_input(44, "x", (2, 24, 50, 20)).cuda().requires_grad_(True)
+    y = ops.rowpool_max(x, 16)
+    g = randn_input(44, "g", (2, 24, 16, 1)).cuda()
+    y.backward(g)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.adaptive_max_pool2d(xr, (16, 1))
+    yr.backward(g)
+    assert torch.equal(y, yr) and torch.allclose(x.grad, xr.grad)
+    a = randn_input(45, "a", (2, 5, 12, 30)).cuda().requires_grad_(True)
+    att = rand_input(45, "att", (2, 5, 12, 1)).cuda().requires_grad_(True)
+    z = ops.mul_rows(a, att)
+    gz = randn_input(45, "gz", (2, 5, 12, 30)).cuda()
+    z.backward(gz)
+    ar, tr = a.detach().clone().requires_grad_(True), att.detach().clone().requires_grad_(True)
+    (ar * tr).backward(gz)
+    assert torch.allclose(z, (ar * tr).detach(), atol=1e-6)
+    assert torch.allclose(a.grad, ar.grad, atol=1e-6) and torch.allclose(att.grad, tr.grad, atol=1e-4)
+    # channel dropout: whole (sample, channel) rows, kept rows scaled by 1/(1-p)
+    d = ops.dropout_channels(torch.ones(64, 32, 8, 1, device="cuda"), 0.25, True, 7)
+    rows = d.squeeze(3).amax(2)
+    assert bool(((d.squeeze(3) == rows.unsqueeze(2)).all()))
+    assert all(v == 0.0 or abs(v - 1.0 / 0.75) < 1e-6 for v in torch.unique(rows).tolist())
+    assert 0.15 < float((rows == 0).float().mean()) < 0.35
+
+
+def test_oracle_minidsnet_hanet_matches_golden():
+    gold = np.load(GOLD)
+    m = fill_state_dict(R.minidsnetExt(R.CFG(aspp=0, hanet=1), labels=2, patch_type='1dcorr'), 43).eval()
+    a, b = rand_input(43, "left", (2, 3, 256, 256)), rand_input(43, "right", (2, 3, 256, 256))
+    with torch.no_grad():
+        outs = m(a, b, _pos(2, 256, 256))
+    for i, name in enumerate(("seg1", "disp", "seg2")):
+        _check(gold, "mini_hanet.eval.%s" % name, outs[i], 2e-4)
+
+
+@pytest.mark.gpu
+def test_hip_minidsnet_hanet_matches_golden():
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    gold = np.load(GOLD)
+    m = fill_state_dict(N.minidsnetExt(R.CFG(aspp=0, hanet=1), labels=2, patch_type='1dcorr'), 43).cuda().eval()
+    a, b = rand_input(43, "left", (2, 3, 256, 256)).cuda(), rand_input(43, "right", (2, 3, 256, 256)).cuda()
+    with torch.no_grad():
+        outs = m(a, b, tuple(t.cuda() for t in _pos(2, 256, 256)))
+    for i, name in enumerate(("seg1", "disp", "seg2")):
+        _check(gold, "mini_hanet.eval.%s" % name, outs[i], 1e-3)

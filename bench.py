@@ -36,6 +36,8 @@ def parse():
                     help="psmnet = BASELINE config 3 (PSMNet(192), build-defined loss: mean L1 of the three predictions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the dominant-kernel microbenchmark (the command profiled under profiles/: tools/roofline_profile.sh)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
     return ap.parse_args()
@@ -81,8 +83,18 @@ def kernel_roofline(dtype, B, H, W):
     flops = 2.0 * B * H * W * C * C * 25
     peak = 2500.0 if dtype == torch.bfloat16 else 157.3
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_fwd_kernel<8x32 tile> 5x5 64->64 @%dx%dx%d" % (B, H, W), "achieved": round(ach, 2),
-            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "ms_per_launch": round(ms, 4)}
+    # HBM bytes per launch of this kernel from the PMC passes committed under profiles/ (FETCH_SIZE doubled as the gfx950
+    # note of MI355X_MICROARCH.md prescribes, + WRITE_SIZE; tools/roofline_profile.sh); null when no profile is committed
+    traffic = None
+    tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_roofline_traffic.json")
+    if dtype == torch.bfloat16 and (B, H, W) == (8, 256, 512) and os.path.exists(tj):
+        try:
+            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "mfma", "kernel": "conv_fast_kernel<bf16, 8x32 tile, 64 out-ch block, LDS-DMA> 5x5 64->64 @%dx%dx%d" % (B, H, W),
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "ms_per_launch": round(ms, 4)}
 
 
 def cpu_baseline(B, H, W, steps, threads=16):
@@ -128,6 +140,10 @@ def main():
         pg = dist.group.WORLD
     from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    if a.roofline_only:
+        import pmt_learning_for_semantic_segmentation_and_disparity_amd  # noqa: F401
+        print(json.dumps({"roofline": kernel_roofline(dtype, a.batch, a.height, a.width)}))
+        return
     model = build_model(dtype, a.model)
     loss_fn = None
     if a.model == "psmnet":

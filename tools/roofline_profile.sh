@@ -1,0 +1,16 @@
+#!/bin/bash
+# Profile of the bench's dominant-kernel microbenchmark (run on the GPU box from the repo root):
+#   1. rocprofv3 --kernel-trace --stats  -> per-kernel average duration (must agree with bench.py's roofline.ms_per_launch)
+#   2. rocprofv3 --pmc FETCH_SIZE        -> HBM read bytes   (separate pass; x2 on gfx950, MI355X_MICROARCH.md §HBM)
+#   3. rocprofv3 --pmc WRITE_SIZE        -> HBM write bytes  (separate pass)
+# plus the kernel statistics of one whole bench run.  Outputs under gpurun_out/roofline/; tools/roofline_collect.py
+# turns them into profiles/r01_roofline_* (committed).
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/roofline
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python bench.py --roofline-only > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o r -- python bench.py --roofline-only > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o r -- python bench.py --roofline-only > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step -o r -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/step.log 2>&1
+tail -1 $OUT/stats.log

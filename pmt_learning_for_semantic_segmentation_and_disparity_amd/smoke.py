@@ -1,5 +1,5 @@
 """One small hot-path invocation on cuda:0, checked against the CPU oracle (imported here only as the checker):
-the correlation operator alone, then ONE training step (forward + loss + backward) of `minidsnetExt` at 1 x 128 x 128 in
+the correlation operator alone, then ONE training step (forward + loss + backward) of `minidsnetExt` at 2 x 256 x 256 in
 fp32 — conv / BatchNorm / pooling / resize / correlation / loss kernels of libsdhip vs oracle/ref_models.py."""
 import torch
 import torch.nn.functional as F
@@ -28,10 +28,10 @@ def _step():
     from oracle.detweights import fill_state_dict, rand_input
     from . import nn as N
     cfg = R.CFG(aspp=0)
-    H = W = 128
-    a, b = rand_input(7, "left", (1, 3, H, W)), rand_input(7, "right", (1, 3, H, W))
-    seg = F.one_hot((rand_input(7, "seg", (1, H, W)) > 0.5).long(), 2).permute(0, 3, 1, 2).float()
-    disp = rand_input(7, "disp", (1, 1, H, W), 0.0, 8.0)
+    H = W = 256   # smallest square the 128-pixel pyramid pool of piramidNet2 accepts (models/dsnet_t2.py:420-470)
+    a, b = rand_input(7, "left", (2, 3, H, W)), rand_input(7, "right", (2, 3, H, W))
+    seg = F.one_hot((rand_input(7, "seg", (2, H, W)) > 0.5).long(), 2).permute(0, 3, 1, 2).float()
+    disp = rand_input(7, "disp", (2, 1, H, W), 0.0, 8.0)
 
     def loss_of(outs, seg, disp):
         ce = lambda y: torch.mean(torch.sum(-seg * F.log_softmax(y.float(), 1), 1))

@@ -174,6 +174,12 @@ int sdhip_stats_replica_sum(const double* ws, double* out, int nrep, int groups,
 /* gout = gin + dstats[g][0][c] + 2*x*dstats[g][1][c]: the gradient that flows through the batch statistics. */
 int sdhip_stats_fix(const void* gin, int ldgi, const void* x, int ldx, void* gout, int ldgo,
                     const double* dstats, int stats_ld, long npix, int C, int groups, int dtype, void* stream);
+/* Two-phase BatchNorm backward, second phase: gx = gy * act'(x*scale+shift) * scale + dstats[g][0] + 2*x*dstats[g][1] in one
+ * pass (first phase: sdhip_affine_act_bwd with gx == NULL, then sdhip_bn_finalize_bwd) — the backward of
+ * nn.BatchNorm2d(+ReLU) in train mode, models/dsnet_t2.py:16-117.  act: 0 none, 1 relu, 2 sigmoid. */
+int sdhip_bn_bwd_apply(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
+                       const float* scale, const float* shift, const double* dstats, int stats_ld,
+                       long npix, int C, int groups, int act, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Pooling / resizing / broadcast product on NHWC tensors (HBM bound).

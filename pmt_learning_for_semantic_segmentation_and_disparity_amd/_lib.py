@@ -75,6 +75,7 @@ SIGNATURES = {
     "sdhip_log_softmax_bwd": [_p, _i, _p, _i, _p, _i, _l, _i, _i, _p],
     "sdhip_l1_loss": [_p, _p, _p, _p, _l, _f, _i, _p],
     "sdhip_stats_fix": [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _i, _i, _p],
+    "sdhip_bn_bwd_apply": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _l, _i, _i, _i, _i, _p],
 }
 _lib.sdhip_lovasz_workspace_bytes.argtypes = [_l, _i]
 _lib.sdhip_lovasz_workspace_bytes.restype = _l

@@ -172,6 +172,56 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const T* gin, int ldgi, 
   }
 }
 
+// Second phase of the two-phase BatchNorm backward: gx = gy * act'(x*scale+shift) * scale + dS1 + 2 * x * dS2 in ONE pass
+// (the first phase is affine_act_bwd with gx == NULL: reductions only).  10 bytes per element instead of the 12 of
+// "write gx, then read it back for the statistics path".
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ gy, int ldg, const T* __restrict__ x, int ldx,
+                                                           T* __restrict__ gx, int ldgx, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const double* __restrict__ dS, int ldc,
+                                                           int C, long npix_g, int act, RowGeom rg) {
+  constexpr int N = Unit<T, VEC>::N;
+  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  const int u = blockIdx.y * rg.tx + tx;
+  if (ty >= rg.ty || u >= rg.units) return;
+  const int g = blockIdx.z, c0 = u * N;
+  float sc[N], sf[N], a[N], b2[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    sc[e] = scale[g * C + c0 + e]; sf[e] = shift[g * C + c0 + e];
+    a[e] = (float)dS[((long)g * 2 + 0) * ldc + c0 + e]; b2[e] = (float)(2.0 * dS[((long)g * 2 + 1) * ldc + c0 + e]);
+  }
+  const long base = (long)g * npix_g;
+  const long stride = (long)gridDim.x * rg.ty;
+  for (long pix0 = (long)blockIdx.x * rg.ty + ty; pix0 < npix_g; pix0 += 4 * stride) {
+    float gv[4][N], xv[4][N];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long pix = pix0 + k * stride;
+      if (pix < npix_g) {
+        Unit<T, VEC>::load(gy + (base + pix) * ldg + c0, gv[k]);
+        Unit<T, VEC>::load(x + (base + pix) * ldx + c0, xv[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long pix = pix0 + k * stride;
+      if (pix < npix_g) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const float z = fmaf(xv[k][e], sc[e], sf[e]);
+          float gm = gv[k][e];
+          if (act == 1) gm = z > 0.f ? gm : 0.f;
+          else if (act == 2) { const float sg = 1.f / (1.f + __expf(-z)); gm *= sg * (1.f - sg); }
+          // the first-phase result the one-pass form would have stored is rounded to T before the statistics path is added
+          gv[k][e] = Elem<T>::rnd(gm * sc[e]) + fmaf(xv[k][e], b2[e], a[e]);
+        }
+        Unit<T, VEC>::store(gx + (base + pix) * ldgx + c0, gv[k]);
+      }
+    }
+  }
+}
+
 // S[g][0][c] += sum x, S[g][1][c] += sum x^2  (f64 atomics)
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, int ldx, double* __restrict__ S, int ldc, int nrep,
@@ -429,6 +479,32 @@ extern "C" int sdhip_stats_fix(const void* gin, int ldgi, const void* x, int ldx
     Plan pl = plan(v ? C / 8 : C, npix / G, G);
     if (v) hipLaunchKernelGGL((stats_fix_kernel<bf16_t, true>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
     else hipLaunchKernelGGL((stats_fix_kernel<bf16_t, false>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+  }
+#undef ARGS
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_bn_bwd_apply(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
+                                  const float* scale, const float* shift, const double* dS, int ldc,
+                                  long npix, int C, int groups, int act, int dtype, void* stream) {
+  if (ldc <= 0) ldc = C;
+  const int G = groups;
+  if (int rc = check_rows("bn_bwd_apply", npix, C, G, dtype)) return rc;
+  SDHIP_CHECK_ARG(gy && x && gx && scale && shift && dS && ldg >= C && ldx >= C && ldgx >= C, "bn_bwd_apply: bad pointers/strides");
+  SDHIP_CHECK_ARG(act == 0 || act == 1 || act == 2, "bn_bwd_apply: activation %d", act);
+  hipStream_t s = (hipStream_t)stream;
+#define ARGS(T) (const T*)gy, ldg, (const T*)x, ldx, (T*)gx, ldgx, scale, shift, dS, ldc, C, npix / G, act
+  if (dtype == SDHIP_F32) {
+    const bool v = vec_rows<float>(C, {ldg, ldx, ldgx}, {gy, x, gx});
+    Plan pl = plan(v ? C / 4 : C, npix / G, G, 1024);
+    if (v) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+  } else {
+    const bool v = vec_rows<bf16_t>(C, {ldg, ldx, ldgx}, {gy, x, gx});
+    Plan pl = plan(v ? C / 8 : C, npix / G, G, 1024);
+    if (v) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
   }
 #undef ARGS
   SDHIP_LAUNCH_CHECK();

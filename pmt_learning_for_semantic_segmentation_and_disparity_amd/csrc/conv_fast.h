@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   const int halo_bytes = ((IH * IWp + (256 >> SH) - 1) & ~((256 >> SH) - 1)) * RB;   // whole load rounds (4 KiB)
   const int wbuf_bytes = ((p.tg * BN + (256 >> SH) - 1) & ~((256 >> SH) - 1)) * RB;
   unsigned char* const halo0 = smem;
-  unsigned char* const wl0 = smem + halo_bytes * (PF ? 2 : 1);
+  unsigned char* const wl0 = smem + halo_bytes * ((PF && nqq > 1) ? 2 : 1);   // a single chunk needs no second halo buffer
 
   f32x4 acc[NT_CO][NT_PIX];
 #pragma unroll

@@ -486,7 +486,8 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
       const int IH = (th - 1) * stride + (kh - 1) * dil + 1, IW = (tw - 1) * stride + (kw - 1) * dil + 1;
       const int IWp = (IW + 7) & ~7;
       const int hrows = ((IH * IWp + px_per_round - 1) / px_per_round) * px_per_round;   // whole load rounds
-      const size_t hb = (size_t)hrows * rb * (fbig ? 1 : 2);
+      const int nqq_f = kd * (ks == 2 ? sdhip_cdiv(Cin, CKh) : 1);
+      const size_t hb = (size_t)hrows * rb * ((fbig || nqq_f == 1) ? 1 : 2);   // small tiles double-buffer the halo across chunks
       if (!fbig && hrows > 5 * px_per_round) { fbig = true; continue; }   // small-tile halo prefetch plan: 5 rounds
       auto wbuf = [&](int tgv) { return (size_t)(((tgv * bn + px_per_round - 1) / px_per_round) * px_per_round) * rb; };
       int tg = T;

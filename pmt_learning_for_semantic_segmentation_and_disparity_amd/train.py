@@ -5,6 +5,7 @@ JPEG work: model(left, right) -> CE(seg1) + CE(seg2) + Lovasz(seg2) + L1(disp) -
 Parameters live in one flat f32 buffer (one fused Adam launch, one gradient all-reduce over RCCL when
 data-parallel); activations run in `dtype` (bf16 MFMA path or exact f32 path).
 """
+import os
 import torch
 
 from . import _lib, ops, parallel
@@ -31,7 +32,7 @@ def flatten_parameters(model):
 
 class TrainStep:
     def __init__(self, model, dtype=torch.bfloat16, lr=0.0015, betas=(0.9, 0.999), eps=1e-7, use_lovasz=True,
-                 use_graph=True, world_size=1, process_group=None, use_side_stream=True, loss_fn=None):
+                 use_graph=True, world_size=1, process_group=None, use_side_stream=False, loss_fn=None):
         self.model, self.dtype, self.use_lovasz = model, dtype, use_lovasz
         self.loss_fn = loss_fn      # (outputs, seg, disp) -> scalar; default: the joint seg+disp loss of the reference step
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -42,7 +43,7 @@ class TrainStep:
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.beta_pow = torch.ones(2, dtype=torch.float32, device=self.flat_p.device)
         self.use_graph = use_graph
-        self.use_side_stream = use_side_stream
+        self.use_side_stream = use_side_stream and not os.environ.get("SDHIP_DIAG_NO_SIDE")   # env: timing diagnostics only
         self.graph = None
         self.static = None
         self.loss = None

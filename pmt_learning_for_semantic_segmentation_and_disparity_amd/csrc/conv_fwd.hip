@@ -453,13 +453,17 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   if ((long)kh * kw * kd * Cin <= 128 && a.Mpad <= 128) bn = a.Mpad > 64 ? 128 : (a.Mpad > 32 ? 64 : (a.Mpad > 16 ? 32 : 16));
   const int T = kh * kw;
   const long blocks_big = (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) * B * Do * sdhip_cdiv(a.Mpad, bn);
-  bool big = (blocks_big >= 512 && Wo >= 24) || getenv("SDHIP_CONV_BIG");
+  static const int tune_big = getenv("SDHIP_TUNE_BIG") ? atoi(getenv("SDHIP_TUNE_BIG")) : 512;
+  static const int tune_split = getenv("SDHIP_TUNE_SPLIT") ? atoi(getenv("SDHIP_TUNE_SPLIT")) : 1024;
+  static const int tune_ksoft_small = getenv("SDHIP_TUNE_KSOFT_SMALL") ? atoi(getenv("SDHIP_TUNE_KSOFT_SMALL")) : 80;
+  static const int tune_ksoft_big = getenv("SDHIP_TUNE_KSOFT_BIG") ? atoi(getenv("SDHIP_TUNE_KSOFT_BIG")) : 80;
+  bool big = (blocks_big >= tune_big && Wo >= 24) || getenv("SDHIP_CONV_BIG");
   if (!big) {
     // small feature maps (DenseNet blocks 2-4, pooled pyramids): the launch cannot fill 256 CUs with pixel tiles alone,
     // so split the output channels over more workgroups (the input tile is re-read from L2, the serial
     // chunk-by-chunk latency chain per workgroup gets shorter and more of them overlap per CU).
     const long px_blocks = (long)sdhip_cdiv(Ho, 4) * sdhip_cdiv(Wo, 16) * B * Do;
-    while (bn > 32 && px_blocks * sdhip_cdiv(a.Mpad, bn) < 1024) bn >>= 1;
+    while (bn > 32 && px_blocks * sdhip_cdiv(a.Mpad, bn) < tune_split) bn >>= 1;
   }
   const int rows = a.Mpad < bn ? a.Mpad : bn;
   const size_t kMax = 160 * 1024, kSoft = 80 * 1024;   // kSoft: two workgroups per CU
@@ -491,7 +495,8 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
       if (!fbig && hrows > 5 * px_per_round) { fbig = true; continue; }   // small-tile halo prefetch plan: 5 rounds
       auto wbuf = [&](int tgv) { return (size_t)(((tgv * bn + px_per_round - 1) / px_per_round) * px_per_round) * rb; };
       int tg = T;
-      while (tg > 1 && hb + 2 * wbuf(tg) > kSoft) --tg;
+      const size_t ksoft_f = (size_t)(fbig ? tune_ksoft_big : tune_ksoft_small) * 1024;
+      while (tg > 1 && hb + 2 * wbuf(tg) > ksoft_f) --tg;
       size_t lds = hb + 2 * wbuf(tg);
       if (lds < 4096) lds = 4096;
       if (lds > kMax) { if (!fbig) break; fbig = false; continue; }

@@ -167,19 +167,35 @@ __global__ __launch_bounds__(256) void softargmin_fwd(const T* __restrict__ cost
 }
 
 // gcost (f32, pre-zeroed, [B][D4][H4][W4]) += d pred / d cost * g
+// One workgroup = an 8 x 32 tile of full-resolution pixels (one per lane).  Their gradients with respect to the
+// low-resolution cost levels land on a small footprint of low-resolution cells ((8*sh+3) x (32*sw+3) cells, 5 x 11 at
+// PSMNet's 1/4 scale): they are summed in LDS (ds_add_f32) and flushed once, contiguous lanes along w4 — ~50x fewer
+// global float atomics than one scattered 4-byte atomic per (pixel, level, bilinear neighbour), which cost 2 ms per call.
+constexpr int kSaTH = 8, kSaTW = 32, kSaCells = 96;
 template <typename T>
 __global__ __launch_bounds__(256) void softargmin_bwd(const T* __restrict__ cost, const T* __restrict__ g, float* __restrict__ gcost,
                                                       int B, int D4, int H4, int W4, int Dout, int H, int W) {
-  __shared__ float cs[kMaxD4][256];   // interpolated low-res column per lane, then reused for its gradient
+  extern __shared__ float sa_dyn[];
+  float (*cs)[256] = reinterpret_cast<float (*)[256]>(sa_dyn);            // [kMaxD4][256] interpolated low-res column per lane
+  float* acc = sa_dyn + kMaxD4 * 256;                                     // [D4][kSaCells] gradient footprint of the tile
   const float sd = (float)D4 / (float)Dout, shh = (float)H4 / (float)H, sw = (float)W4 / (float)W;
-  const long npix = (long)B * H * W;
-  for (long p0 = (long)blockIdx.x * 256; p0 < npix; p0 += (long)gridDim.x * 256) {
-    const long p = p0 + threadIdx.x;
-    const bool live = p < npix;
-    const int w = live ? (int)(p % W) : 0;
-    const int h = live ? (int)((p / W) % H) : 0;
-    const long b = live ? p / ((long)W * H) : 0;
-    const Lin lh = lin_src(h, shh, H4), lw = lin_src(w, sw, W4);
+  const int tiles_w = (W + kSaTW - 1) / kSaTW, tiles_h = (H + kSaTH - 1) / kSaTH;
+  const long ntiles = (long)B * tiles_h * tiles_w;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long b = tile / ((long)tiles_h * tiles_w);
+    const int tr = (int)(tile - b * tiles_h * tiles_w);
+    const int h0 = (tr / tiles_w) * kSaTH, w0 = (tr % tiles_w) * kSaTW;
+    const int h1 = min(h0 + kSaTH, H) - 1, w1 = min(w0 + kSaTW, W) - 1;
+    // footprint of the tile on the low-resolution grid (source indices are monotone in the pixel coordinate)
+    const int hb = lin_src(h0, shh, H4).i0, he = lin_src(h1, shh, H4).i1;
+    const int wb = lin_src(w0, sw, W4).i0, we = lin_src(w1, sw, W4).i1;
+    const int ch = he - hb + 1, cw = we - wb + 1, ncell = ch * cw;
+    const bool lds_ok = ncell <= kSaCells;                                 // uniform; odd scale factors fall back to global atomics
+    if (lds_ok) for (int i = threadIdx.x; i < D4 * ncell; i += 256) acc[i] = 0.f;
+    const int h = h0 + threadIdx.x / kSaTW, w = w0 + threadIdx.x % kSaTW;
+    const bool live = h < H && w < W;
+    const long p = (b * H + (live ? h : h0)) * (long)W + (live ? w : w0);
+    const Lin lh = lin_src(live ? h : h0, shh, H4), lw = lin_src(live ? w : w0, sw, W4);
     const float w00 = (1.f - lh.l1) * (1.f - lw.l1), w01 = (1.f - lh.l1) * lw.l1, w10 = lh.l1 * (1.f - lw.l1), w11 = lh.l1 * lw.l1;
     for (int d4 = 0; d4 < D4; ++d4) {
       const T* c = cost + ((b * D4 + d4) * H4) * (long)W4;
@@ -196,34 +212,48 @@ __global__ __launch_bounds__(256) void softargmin_bwd(const T* __restrict__ cost
     }
     const float predv = e / s, inv = 1.f / s;
     const float gv = live ? Elem<T>::ld(g + p) : 0.f;
-    // d pred / d v_d = p_d (d - pred); fold the depth interpolation back onto the D4 levels.  Two passes over d keep the
-    // column values readable while their gradients are accumulated in registers of the SAME levels (i0 is monotone in d).
-    float acc0 = 0.f;      // gradient of level `cur`
-    float acc1 = 0.f;      // gradient of level `cur + 1`
+    __syncthreads();   // acc is zeroed
+    const int c00 = (lh.i0 - hb) * cw + (lw.i0 - wb), c01 = (lh.i0 - hb) * cw + (lw.i1 - wb);
+    const int c10 = (lh.i1 - hb) * cw + (lw.i0 - wb), c11 = (lh.i1 - hb) * cw + (lw.i1 - wb);
+    auto scatter = [&](int level, float a) {
+      if (!live || a == 0.f) return;
+      if (lds_ok) {
+        float* al = acc + level * ncell;
+        atomicAdd(al + c00, w00 * a); atomicAdd(al + c01, w01 * a); atomicAdd(al + c10, w10 * a); atomicAdd(al + c11, w11 * a);
+      } else {
+        float* gc = gcost + ((b * D4 + level) * H4) * (long)W4;
+        atomicAdd(gc + lh.i0 * W4 + lw.i0, w00 * a); atomicAdd(gc + lh.i0 * W4 + lw.i1, w01 * a);
+        atomicAdd(gc + lh.i1 * W4 + lw.i0, w10 * a); atomicAdd(gc + lh.i1 * W4 + lw.i1, w11 * a);
+      }
+    };
+    // d pred / d v_d = p_d (d - pred); fold the depth interpolation back onto the D4 levels.  The gradients of levels
+    // `cur` and `cur + 1` are accumulated in registers (i0 is monotone in d) and scattered when a level is complete.
+    float acc0 = 0.f, acc1 = 0.f;
     int cur = 0;
     for (int d = 0; d < Dout; ++d) {
       const Lin ld = lin_src(d, sd, D4);
       const float v = (1.f - ld.l1) * cs[ld.i0][threadIdx.x] + ld.l1 * cs[ld.i1][threadIdx.x];
       const float dv = gv * __expf(v - m) * inv * ((float)d - predv);
-      while (cur < ld.i0) {   // level `cur` is complete: scatter it to the 4 low-resolution neighbours
-        if (live && acc0 != 0.f) {
-          float* gc = gcost + ((b * D4 + cur) * H4) * (long)W4;
-          atomicAdd(gc + lh.i0 * W4 + lw.i0, w00 * acc0); atomicAdd(gc + lh.i0 * W4 + lw.i1, w01 * acc0);
-          atomicAdd(gc + lh.i1 * W4 + lw.i0, w10 * acc0); atomicAdd(gc + lh.i1 * W4 + lw.i1, w11 * acc0);
-        }
-        acc0 = acc1; acc1 = 0.f; ++cur;
-      }
+      while (cur < ld.i0) { scatter(cur, acc0); acc0 = acc1; acc1 = 0.f; ++cur; }
       acc0 += (1.f - ld.l1) * dv;
       if (ld.i1 != ld.i0) acc1 += ld.l1 * dv; else acc0 += ld.l1 * dv;
     }
     for (int k = 0; k < 2; ++k) {   // flush the last two levels
-      if (live && cur < D4 && acc0 != 0.f) {
-        float* gc = gcost + ((b * D4 + cur) * H4) * (long)W4;
-        atomicAdd(gc + lh.i0 * W4 + lw.i0, w00 * acc0); atomicAdd(gc + lh.i0 * W4 + lw.i1, w01 * acc0);
-        atomicAdd(gc + lh.i1 * W4 + lw.i0, w10 * acc0); atomicAdd(gc + lh.i1 * W4 + lw.i1, w11 * acc0);
-      }
+      if (cur < D4) scatter(cur, acc0);
       acc0 = acc1; acc1 = 0.f; ++cur;
     }
+    __syncthreads();
+    if (lds_ok) {
+      for (int i = threadIdx.x; i < D4 * ncell; i += 256) {
+        const float v = acc[i];
+        if (v != 0.f) {
+          const int level = i / ncell, cell = i - level * ncell;
+          const int hh = hb + cell / cw, ww = wb + cell % cw;
+          atomicAdd(gcost + (((b * D4 + level) * H4 + hh) * (long)W4 + ww), v);
+        }
+      }
+    }
+    __syncthreads();   // acc / cs are reused by the next tile
   }
 }
 
@@ -312,11 +342,22 @@ extern "C" int sdhip_softargmin_bwd(const void* cost, const void* gpred, void* g
   hipStream_t st = (hipStream_t)stream;
   const long nv = (long)B * D4 * H4 * W4, np = (long)B * H * W;
   if (hipMemsetAsync(gcost_f32, 0, nv * sizeof(float), st) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "softargmin_bwd: memset failed");
+  const size_t sa_lds = ((size_t)kMaxD4 * 256 + (size_t)kMaxD4 * kSaCells) * sizeof(float);
+  static bool sa_attr = false;
+  if (!sa_attr) {
+    if (hipFuncSetAttribute((const void*)softargmin_bwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)softargmin_bwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa_lds) != hipSuccess)
+      SDHIP_FAIL(SDHIP_ERR_LAUNCH, "softargmin_bwd: cannot raise dynamic LDS limit");
+    sa_attr = true;
+  }
+  const long sa_tiles = (long)B * sdhip_cdiv(H, kSaTH) * sdhip_cdiv(W, kSaTW);
+  const int sa_grid = (int)(sa_tiles < 2048 ? sa_tiles : 2048);
+  (void)np;
   if (dtype == SDHIP_F32) {
-    hipLaunchKernelGGL(softargmin_bwd<float>, grid_for(np), dim3(256), 0, st, (const float*)cost, (const float*)gpred, gcost_f32, B, D4, H4, W4, Dout, H, W);
+    hipLaunchKernelGGL(softargmin_bwd<float>, dim3(sa_grid), dim3(256), sa_lds, st, (const float*)cost, (const float*)gpred, gcost_f32, B, D4, H4, W4, Dout, H, W);
     hipLaunchKernelGGL(f32_to_T_kernel<float>, grid_for(nv), dim3(256), 0, st, gcost_f32, (float*)gcost, nv);
   } else {
-    hipLaunchKernelGGL(softargmin_bwd<bf16_t>, grid_for(np), dim3(256), 0, st, (const bf16_t*)cost, (const bf16_t*)gpred, gcost_f32, B, D4, H4, W4, Dout, H, W);
+    hipLaunchKernelGGL(softargmin_bwd<bf16_t>, dim3(sa_grid), dim3(256), sa_lds, st, (const bf16_t*)cost, (const bf16_t*)gpred, gcost_f32, B, D4, H4, W4, Dout, H, W);
     hipLaunchKernelGGL(f32_to_T_kernel<bf16_t>, grid_for(nv), dim3(256), 0, st, gcost_f32, (bf16_t*)gcost, nv);
   }
   SDHIP_LAUNCH_CHECK();

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   for (int j = 0; j < XR; ++j) {
     const int row = rsub + j * RPR;
     const int ih = fast_div(row, IWp, magic_iwp), iw = row - ih * IWp;
-    xo[j] = (okx && row < h_rows) ? (ih * p.W + iw) * p.ldx : 0;
+    xo[j] = (okx && row < h_rows && iw < IW) ? (ih * p.W + iw) * p.ldx : 0;   // dead pitch columns re-read the tile's first pixel (no traffic)
   }
 #pragma unroll
   for (int j = 0; j < y_rounds; ++j) {

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdhip.so")
 
 F32, BF16 = 0, 1
-NREP = 32   # statistics replicas (SDHIP_NREP in csrc/conv_common.h)
+NREP = int(os.environ.get("SDHIP_TUNE_NREP", "32"))   # statistics replicas the kernels spread their atomics over (env: tuning only)
 
 
 class SdhipError(RuntimeError):

@@ -180,6 +180,21 @@ int sdhip_stats_fix(const void* gin, int ldgi, const void* x, int ldx, void* gou
 int sdhip_bn_bwd_apply(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
                        const float* scale, const float* shift, const double* dstats, int stats_ld,
                        long npix, int C, int groups, int act, int dtype, void* stream);
+/* Consumer-side finalize (no separate per-channel launch between a reduction and the pass that uses it):
+ * affine_act_bn   : y = act(BatchNorm_train(x)) (+ res) straight from the statistics of x (as written by the conv epilogue /
+ *                   sdhip_channel_stats); also writes scale/shift/mean/invstd [G][C] for the backward pass and updates
+ *                   running_mean / running_var (groups applied in order, momentum as nn.BatchNorm2d) — the forward of
+ *                   convbn/deconvbn + ReLU (+ skip add), models/dsnet_t2.py:16-117.
+ * bn_bwd_apply_fin: sdhip_bn_bwd_apply with dstats derived in the kernel from the (dscale, dshift) replica sums of
+ *                   sdhip_affine_act_bwd; writes (accumulate_params: adds to) dgamma / dbeta summed over groups. */
+int sdhip_affine_act_bn(const void* x, int ldx, void* y, int ldy, const void* res, int ldr,
+                        const double* stats, int stats_ld, int nrep, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float* scale, float* shift, float* mean_out, float* invstd_out,
+                        long npix, int C, int groups, double count, float eps, float momentum, int act, int dtype, void* stream);
+int sdhip_bn_bwd_apply_fin(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
+                           const float* scale, const float* shift, const float* dscale, const float* dshift, int nrep,
+                           const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                           int accumulate_params, long npix, int C, int groups, double count, int act, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Pooling / resizing / broadcast product on NHWC tensors (HBM bound).

@@ -222,6 +222,192 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ---- consumer-side finalize: the per-channel kernels between a reduction and the pass that uses its result are pure
+// launch latency (~5 us + a graph node each, ~400 per training step).  These variants let every workgroup of the
+// elementwise pass derive the coefficients of ITS channel slice from the replica sums (a few KB from L2), and let the
+// first workgroup of each slice publish them / update the parameters' side outputs.
+
+// y = act(BatchNorm_train(x)) (+ res) straight from the statistics S (f64 [nrep][G][2][ldc]) of x.
+// Also writes scale/shift/mean/invstd ([G][C], for the backward pass) and updates the running statistics (groups in order).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void affine_act_bn_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                            const T* __restrict__ res, int ldr,
+                                                            const double* __restrict__ S, int ldc, int nrep,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ rmean, float* __restrict__ rvar,
+                                                            float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                                            float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                            int C, long npix_g, double count, float eps, float momentum, int act, RowGeom rg) {
+  constexpr int N = Unit<T, VEC>::N;
+  __shared__ float s_sc[64 * 8], s_sf[64 * 8];
+  __shared__ double s_red[2][8][32];
+  const int G = gridDim.z, g = blockIdx.z;
+  const int ch0 = blockIdx.y * rg.tx * N;
+  const int nch = min(rg.tx, rg.units - (int)blockIdx.y * rg.tx) * N;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const bool writer = blockIdx.x == 0 && g == 0 && rmean;   // wave-uniform per workgroup: running statistics of the slice
+  for (int cb = 0; cb < nch; cb += 32) {
+    const int c = ch0 + cb + cl;
+    const bool okc = cb + cl < nch && c < C;
+    float rm = 0.f, rv = 0.f;
+    if (writer && rl == 0 && okc) { rm = rmean[c]; rv = rvar[c]; }
+    for (int gg = 0; gg < G; ++gg) {
+      if (gg != g && !writer) continue;                      // everybody needs its own group; the writer all, in order
+      double a1 = 0., a2 = 0.;
+      if (okc) {
+        for (int r = rl; r < nrep; r += 8) {
+          const double* Sr = S + (long)r * G * 2 * ldc;
+          a1 += Sr[((long)gg * 2 + 0) * ldc + c];
+          a2 += Sr[((long)gg * 2 + 1) * ldc + c];
+        }
+      }
+      __syncthreads();
+      s_red[0][rl][cl] = a1; s_red[1][rl][cl] = a2;
+      __syncthreads();
+      if (rl == 0 && okc) {
+        double s1 = 0., s2 = 0.;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { s1 += s_red[0][r][cl]; s2 += s_red[1][r][cl]; }
+        const double mu = s1 / count;
+        double var = s2 / count - mu * mu;
+        if (var < 0.) var = 0.;
+        if (gg == g) {
+          const float inv = (float)(1.0 / sqrt(var + (double)eps));
+          const float sc = (gamma ? gamma[c] : 1.f) * inv;
+          const float sf = (float)((double)(beta ? beta[c] : 0.f) - mu * (double)sc);
+          s_sc[cb + cl] = sc; s_sf[cb + cl] = sf;
+          if (blockIdx.x == 0) {
+            scale_out[g * C + c] = sc; shift_out[g * C + c] = sf; mean_out[g * C + c] = (float)mu; invstd_out[g * C + c] = inv;
+          }
+        }
+        if (writer) {
+          const double unb = count > 1. ? var * count / (count - 1.) : var;
+          rm = (1.f - momentum) * rm + momentum * (float)mu;
+          rv = (1.f - momentum) * rv + momentum * (float)unb;
+        }
+      }
+    }
+    if (writer && rl == 0 && okc) { rmean[c] = rm; rvar[c] = rv; }
+  }
+  __syncthreads();
+  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  const int u = blockIdx.y * rg.tx + tx;
+  if (ty >= rg.ty || u >= rg.units) return;
+  const int c0 = u * N;
+  float sc[N], sf[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { sc[e] = s_sc[tx * N + e]; sf[e] = s_sf[tx * N + e]; }
+  const long base = (long)g * npix_g;
+  for (long pix = (long)blockIdx.x * rg.ty + ty; pix < npix_g; pix += (long)gridDim.x * rg.ty) {
+    float f[N], r[N];
+    Unit<T, VEC>::load(x + (base + pix) * ldx + c0, f);
+    if (res) Unit<T, VEC>::load(res + (base + pix) * ldr + c0, r);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      float v = fmaf(f[e], sc[e], sf[e]);
+      if (act == 1) v = fmaxf(v, 0.f);
+      else if (act == 2) v = 1.f / (1.f + __expf(-v));
+      if (res) v += r[e];
+      f[e] = v;
+    }
+    Unit<T, VEC>::store(y + (base + pix) * ldy + c0, f);
+  }
+}
+
+// gx = gy * act'(x*scale+shift) * scale + dS1 + 2*x*dS2 with dS derived in the kernel from the (dscale, dshift) replica
+// sums of the first phase; the first workgroup of a channel slice also writes dgamma / dbeta (summed over groups).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* gy, int ldg, const T* __restrict__ x, int ldx,
+                                                               T* gx, int ldgx, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ dscale,
+                                                               const float* __restrict__ dshift, int nrep,
+                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int acc_par, int C, long npix_g,
+                                                               double inv_count, int act, RowGeom rg) {
+  constexpr int N = Unit<T, VEC>::N;
+  __shared__ float s_a[64 * 8], s_b2[64 * 8];
+  __shared__ float s_red[2][8][32];
+  const int G = gridDim.z, g = blockIdx.z;
+  const int ch0 = blockIdx.y * rg.tx * N;
+  const int nch = min(rg.tx, rg.units - (int)blockIdx.y * rg.tx) * N;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const bool writer = blockIdx.x == 0 && g == 0 && dgamma;     // wave-uniform per workgroup
+  for (int cb = 0; cb < nch; cb += 32) {
+    const int c = ch0 + cb + cl;
+    const bool okc = cb + cl < nch && c < C;
+    float dg = 0.f, db = 0.f;
+    for (int gg = 0; gg < G; ++gg) {
+      if (gg != g && !writer) continue;                         // everybody needs its own group; the writer all of them
+      float ds = 0.f, dh = 0.f;
+      if (okc)
+        for (int r = rl; r < nrep; r += 8) { ds += dscale[((long)r * G + gg) * C + c]; dh += dshift[((long)r * G + gg) * C + c]; }
+      __syncthreads();
+      s_red[0][rl][cl] = ds; s_red[1][rl][cl] = dh;
+      __syncthreads();
+      if (rl == 0 && okc) {
+        ds = 0.f; dh = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { ds += s_red[0][r][cl]; dh += s_red[1][r][cl]; }
+        const float gm = gamma ? gamma[c] : 1.f;
+        const float mu = mean[gg * C + c], inv = invstd[gg * C + c];
+        const float t = ds - mu * dh;
+        dg += inv * t; db += dh;
+        if (gg == g) {
+          const double dinv = (double)gm * t;
+          const double dvar = -0.5 * dinv * (double)inv * inv * inv;
+          const double dmu = -(double)gm * inv * dh - 2.0 * mu * dvar;
+          s_a[cb + cl] = (float)(dmu * inv_count);
+          s_b2[cb + cl] = (float)(2.0 * dvar * inv_count);
+        }
+      }
+    }
+    if (writer && rl == 0 && okc) {
+      dgamma[c] = acc_par ? dgamma[c] + dg : dg;
+      dbeta[c] = acc_par ? dbeta[c] + db : db;
+    }
+  }
+  __syncthreads();
+  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  const int u = blockIdx.y * rg.tx + tx;
+  if (ty >= rg.ty || u >= rg.units) return;
+  const int c0 = u * N;
+  float sc[N], sf[N], a[N], b2[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    sc[e] = scale[g * C + c0 + e]; sf[e] = shift[g * C + c0 + e];
+    a[e] = s_a[tx * N + e]; b2[e] = s_b2[tx * N + e];
+  }
+  const long base = (long)g * npix_g;
+  const long stride = (long)gridDim.x * rg.ty;
+  for (long pix0 = (long)blockIdx.x * rg.ty + ty; pix0 < npix_g; pix0 += 4 * stride) {
+    float gv[4][N], xv[4][N];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long pix = pix0 + k * stride;
+      if (pix < npix_g) {
+        Unit<T, VEC>::load(gy + (base + pix) * ldg + c0, gv[k]);
+        Unit<T, VEC>::load(x + (base + pix) * ldx + c0, xv[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long pix = pix0 + k * stride;
+      if (pix < npix_g) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const float z = fmaf(xv[k][e], sc[e], sf[e]);
+          float gm = gv[k][e];
+          if (act == 1) gm = z > 0.f ? gm : 0.f;
+          else if (act == 2) { const float sg = 1.f / (1.f + __expf(-z)); gm *= sg * (1.f - sg); }
+          gv[k][e] = Elem<T>::rnd(gm * sc[e]) + fmaf(xv[k][e], b2[e], a[e]);
+        }
+        Unit<T, VEC>::store(gx + (base + pix) * ldgx + c0, gv[k]);
+      }
+    }
+  }
+}
+
 // S[g][0][c] += sum x, S[g][1][c] += sum x^2  (f64 atomics)
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, int ldx, double* __restrict__ S, int ldc, int nrep,
@@ -377,6 +563,9 @@ Plan plan(int units, long npix_g, int G, int max_blocks = 2048) {
   return p;
 }
 
+// workgroups of the consumer-side-finalize kernels: each one re-derives its coefficients from the replica sums (KBs from L2)
+int tune_fused_blocks() { static const int v = getenv("SDHIP_TUNE_FUSED_BLOCKS") ? atoi(getenv("SDHIP_TUNE_FUSED_BLOCKS")) : 768; return v; }
+
 int check_rows(const char* who, long npix, int C, int G, int dtype) {
   SDHIP_CHECK_ARG(npix > 0 && C > 0 && G >= 1 && npix % G == 0, "%s: bad shape npix=%ld C=%d groups=%d", who, npix, C, G);
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "%s: unknown dtype %d", who, dtype);
@@ -505,6 +694,68 @@ extern "C" int sdhip_bn_bwd_apply(const void* gy, int ldg, const void* x, int ld
     Plan pl = plan(v ? C / 8 : C, npix / G, G, 1024);
     if (v) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+  }
+#undef ARGS
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_affine_act_bn(const void* x, int ldx, void* y, int ldy, const void* res, int ldr,
+                                   const double* stats, int ldc, int nrep, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float* scale, float* shift, float* mean_out,
+                                   float* invstd_out, long npix, int C, int groups, double count, float eps, float momentum,
+                                   int act, int dtype, void* stream) {
+  if (ldc <= 0) ldc = C;
+  if (nrep < 1) nrep = 1;
+  const int G = groups;
+  if (int rc = check_rows("affine_act_bn", npix, C, G, dtype)) return rc;
+  SDHIP_CHECK_ARG(x && y && stats && scale && shift && mean_out && invstd_out && ldx >= C && ldy >= C && (!res || ldr >= C),
+                  "affine_act_bn: bad pointers/strides");
+  SDHIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && count > 0., "affine_act_bn: bad statistics arguments");
+  hipStream_t s = (hipStream_t)stream;
+#define ARGS(T) (const T*)x, ldx, (T*)y, ldy, (const T*)res, ldr, stats, ldc, nrep, gamma, beta, running_mean, running_var, \
+                scale, shift, mean_out, invstd_out, C, npix / G, count, eps, momentum, act
+  if (dtype == SDHIP_F32) {
+    const bool v = vec_rows<float>(C, {ldx, ldy, res ? ldr : 0}, {x, y, res});
+    Plan pl = plan(v ? C / 4 : C, npix / G, G, tune_fused_blocks());
+    if (v) hipLaunchKernelGGL((affine_act_bn_kernel<float, true>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+    else hipLaunchKernelGGL((affine_act_bn_kernel<float, false>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+  } else {
+    const bool v = vec_rows<bf16_t>(C, {ldx, ldy, res ? ldr : 0}, {x, y, res});
+    Plan pl = plan(v ? C / 8 : C, npix / G, G, tune_fused_blocks());
+    if (v) hipLaunchKernelGGL((affine_act_bn_kernel<bf16_t, true>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+    else hipLaunchKernelGGL((affine_act_bn_kernel<bf16_t, false>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+  }
+#undef ARGS
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+extern "C" int sdhip_bn_bwd_apply_fin(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
+                                      const float* scale, const float* shift, const float* dscale, const float* dshift, int nrep,
+                                      const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                      int accumulate_params, long npix, int C, int groups, double count, int act, int dtype,
+                                      void* stream) {
+  if (nrep < 1) nrep = 1;
+  const int G = groups;
+  if (int rc = check_rows("bn_bwd_apply_fin", npix, C, G, dtype)) return rc;
+  SDHIP_CHECK_ARG(gy && x && gx && scale && shift && dscale && dshift && mean && invstd && ldg >= C && ldx >= C && ldgx >= C,
+                  "bn_bwd_apply_fin: bad pointers/strides");
+  SDHIP_CHECK_ARG((act == 0 || act == 1 || act == 2) && count > 0. && (dgamma == nullptr) == (dbeta == nullptr),
+                  "bn_bwd_apply_fin: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+#define ARGS(T) (const T*)gy, ldg, (const T*)x, ldx, (T*)gx, ldgx, scale, shift, dscale, dshift, nrep, gamma, mean, invstd, \
+                dgamma, dbeta, accumulate_params, C, npix / G, 1.0 / count, act
+  if (dtype == SDHIP_F32) {
+    const bool v = vec_rows<float>(C, {ldg, ldx, ldgx}, {gy, x, gx});
+    Plan pl = plan(v ? C / 4 : C, npix / G, G, tune_fused_blocks());
+    if (v) hipLaunchKernelGGL((bn_bwd_apply_fin_kernel<float, true>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+    else hipLaunchKernelGGL((bn_bwd_apply_fin_kernel<float, false>), pl.grid, dim3(256), 0, s, ARGS(float), pl.rg);
+  } else {
+    const bool v = vec_rows<bf16_t>(C, {ldg, ldx, ldgx}, {gy, x, gx});
+    Plan pl = plan(v ? C / 8 : C, npix / G, G, tune_fused_blocks());
+    if (v) hipLaunchKernelGGL((bn_bwd_apply_fin_kernel<bf16_t, true>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
+    else hipLaunchKernelGGL((bn_bwd_apply_fin_kernel<bf16_t, false>), pl.grid, dim3(256), 0, s, ARGS(bf16_t), pl.rg);
   }
 #undef ARGS
   SDHIP_LAUNCH_CHECK();

@@ -123,10 +123,14 @@ class _DenseBlockFn(torch.autograd.Function):
                              False, 1, 0, False)
             gw2 = _wgrad(y1, mid, dy2, growth, layer.conv2.weight, B, H, W, mid, growth, 3, 1, sc2, sh2, groups, dt)
             # (3) through relu + norm2's affine, (4) norm2's statistics, (5) into y1
-            dg2, db2, dS2 = ops._bn_backward(gp2, mid, y1, mid, gp2, mid, sc2, sh2, mu2, iv2, layer.norm2.weight, npix, mid,
-                                             groups, 1, count, training, dt, beta=layer.norm2.bias)
-            if training:
-                call("sdhip_stats_fix", ptr(gp2), mid, ptr(y1), mid, ptr(gp2), mid, ptr(dS2), mid, npix, mid, groups, dt, st)
+            if training and ops.parallel.world_size() == 1:
+                dg2, db2 = ops.bn_backward_two_phase(gp2, mid, y1, mid, gp2, mid, sc2, sh2, mu2, iv2, layer.norm2.weight,
+                                                     layer.norm2.bias, npix, mid, groups, 1, count, dt)   # in place: elementwise
+            else:
+                dg2, db2, dS2 = ops._bn_backward(gp2, mid, y1, mid, gp2, mid, sc2, sh2, mu2, iv2, layer.norm2.weight, npix, mid,
+                                                 groups, 1, count, training, dt, beta=layer.norm2.bias)
+                if training:
+                    call("sdhip_stats_fix", ptr(gp2), mid, ptr(y1), mid, ptr(gp2), mid, ptr(dS2), mid, npix, mid, groups, dt, st)
             # (6) conv1 (1x1): data gradient w.r.t. relu(norm1(slab[:Cin])), weight gradient
             wd1 = ops.packed_weight(layer.conv1.weight, 'conv', 'dgrad', dtype)
             gp1 = ops.empty_nhwc(B, Cin, H, W, dtype, dev)

@@ -356,6 +356,37 @@ def _bn_finalize(stats, nrep, bn, count, groups, synced=False):
     return out
 
 
+def _bn_track(bn, groups):
+    """BatchNorm.num_batches_tracked bookkeeping of one train-mode normalisation (see _bn_finalize)."""
+    if bn.num_batches_tracked is None:
+        return
+    c = _ctx[0]
+    if c is not None and c.nbt is not None and c.arena is not None:
+        return                                                    # applied by one multi-tensor add per step (train.TrainStep)
+    if c is not None and c.nbt is not None:
+        c.nbt.append((bn.num_batches_tracked, groups))           # recorded during the measuring step
+    bn.num_batches_tracked += groups
+
+
+def bn_backward_two_phase(gy, ldg, x, ldx, gx, ldgx, scale, shift, mean, invstd, gamma, beta, npix, C, groups, act, count, dt):
+    """Train-mode backward of y = act(BatchNorm(x)) on one GPU: (1) reductions only, (2) ONE pass that derives the
+    statistics gradient from the replica sums itself and writes the complete gradient of x (+ dgamma / dbeta).
+    Returns (dgamma, dbeta), each None when accumulated straight into the flat gradient buffer."""
+    dev = scale.device
+    both, pz = _zeros((2, NREP, groups, C), torch.float32, dev)
+    dsc, dsh = both[0], both[1]
+    call("sdhip_affine_act_bwd", ptr(gy), ldg, ptr(x), ldx, None, 0, ptr(scale), ptr(shift), ptr(dsc), ptr(dsh), NREP,
+         npix, C, groups, act, 0, int(pz), dt, stream_ptr())
+    tg, tb = _grad_target(gamma), _grad_target(beta)
+    direct = tg is not None and tb is not None
+    dgamma = tg if direct else torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = tb if direct else torch.empty(C, dtype=torch.float32, device=dev)
+    call("sdhip_bn_bwd_apply_fin", ptr(gy), ldg, ptr(x), ldx, ptr(gx), ldgx, ptr(scale), ptr(shift), ptr(dsc), ptr(dsh), NREP,
+         ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), int(direct), npix, C, groups, float(count), act, dt,
+         stream_ptr())
+    return (None, None) if direct else (dgamma, dbeta)
+
+
 def _bn_backward(gy, ldg, x, ldx, gx, ldgx, scale, shift, mean, invstd, gamma, npix, C, groups, act, count, train,
                  dt, accumulate_gx=False, dstats=None, accumulate_dstats=False, beta=None):
     """Backward of y = act(x*scale + shift) with scale/shift from batch statistics.
@@ -537,11 +568,20 @@ class _ConvBNActFn(torch.autograd.Function):
         _conv_launch(xv, ldx, wp, yraw, ldr_, None, None, None, ws, Btrue, H, W, Cin, spec.Ho, spec.Wo, Cout,
                      spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, groups, 0, False, NREP, spec.depth())
         count = (B // groups) * spec.Ho * spec.Wo
-        scale, shift, mean, invstd = _bn_finalize(ws, NREP, bn, count, groups)
         rv, ldr = nhwc_view(residual) if residual is not None else (None, 0)
         y, ldy = alloc_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
-        call("sdhip_affine_act", ptr(yraw), ldr_, ptr(y), ldy, ptr(rv), ldr, ptr(scale), ptr(shift), B * spec.Ho * spec.Wo,
-             Cout, groups, act, dtype_code(x), stream_ptr())
+        if train and parallel.world_size() == 1:
+            # one launch: every workgroup derives scale/shift of its channels from the statistics the conv just wrote
+            scale, shift, mean, invstd = [torch.empty((groups, Cout), dtype=torch.float32, device=x.device) for _ in range(4)]
+            _bn_track(bn, groups)
+            call("sdhip_affine_act_bn", ptr(yraw), ldr_, ptr(y), ldy, ptr(rv), ldr, ptr(ws), ws.stride(-2), NREP, ptr(bn.weight),
+                 ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                 B * spec.Ho * spec.Wo, Cout, groups, float(count), float(bn.eps), float(0.1 if bn.momentum is None else bn.momentum),
+                 act, dtype_code(x), stream_ptr())
+        else:
+            scale, shift, mean, invstd = _bn_finalize(ws, NREP, bn, count, groups)
+            call("sdhip_affine_act", ptr(yraw), ldr_, ptr(y), ldy, ptr(rv), ldr, ptr(scale), ptr(shift), B * spec.Ho * spec.Wo,
+                 Cout, groups, act, dtype_code(x), stream_ptr())
         ctx.spec, ctx.act, ctx.groups, ctx.ldx, ctx.count, ctx.train = spec, act, groups, ldx, count, train
         ctx.ldraw = ldr_
         ctx.has_res = residual is not None
@@ -559,7 +599,10 @@ class _ConvBNActFn(torch.autograd.Function):
         g, ldg = nhwc_view(gy)
         graw, ldgr = alloc_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
         ldraw = ctx.ldraw
-        if ctx.train and ctx.act in (0, 1, 2):
+        if ctx.train and ctx.act in (0, 1, 2) and parallel.world_size() == 1:
+            dgamma, dbeta = bn_backward_two_phase(g, ldg, yraw, ldraw, graw, ldgr, scale, shift, mean, invstd, gamma, beta, npix,
+                                                  Cout, groups, ctx.act, ctx.count, dt)
+        elif ctx.train and ctx.act in (0, 1, 2):
             # two-phase: reductions only (no gradient written), per-channel finalize, then ONE pass writes the complete
             # gradient of the conv output — 10 bytes per element instead of 12
             dgamma, dbeta, dS = _bn_backward(g, ldg, yraw, ldraw, None, 0, scale, shift, mean, invstd, gamma, npix, Cout,

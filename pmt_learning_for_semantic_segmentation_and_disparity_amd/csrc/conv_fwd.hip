@@ -496,8 +496,13 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
       auto wbuf = [&](int tgv) { return (size_t)(((tgv * bn + px_per_round - 1) / px_per_round) * px_per_round) * rb; };
       int tg = T;
       const size_t ksoft_f = (size_t)(fbig ? tune_ksoft_big : tune_ksoft_small) * 1024;
-      while (tg > 1 && hb + 2 * wbuf(tg) > ksoft_f) --tg;
-      size_t lds = hb + 2 * wbuf(tg);
+      size_t lds;
+      if (nqq_f == 1 && hb + wbuf(T) <= ksoft_f) {
+        lds = hb + wbuf(T);              // the whole kernel is ONE stage: all taps resident, no second weight buffer
+      } else {
+        while (tg > 1 && hb + 2 * wbuf(tg) > ksoft_f) --tg;
+        lds = hb + 2 * wbuf(tg);
+      }
       if (lds < 4096) lds = 4096;
       if (lds > kMax) { if (!fbig) break; fbig = false; continue; }
       f.tg = tg;

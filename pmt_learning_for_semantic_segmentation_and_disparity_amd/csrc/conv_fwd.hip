@@ -16,6 +16,7 @@
 // sum / sum-of-squares for the BatchNorm that follows).
 #include "conv_common.h"
 #include "conv_fast.h"
+#include "conv_thin.h"
 
 namespace {
 
@@ -471,6 +472,21 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   const int chunks_per_row = Cin <= CKh / 2 ? 4 : 8;
   hipStream_t s = (hipStream_t)stream;
   const int per_tap_any = (kh > 1 || kw > 1) && dil >= 4 && kd == 1;
+  // ---- thin path (conv_thin.h): <= 8 input channels -> 1 output channel on the vector ALUs ----
+  if (Cout == 1 && Cin <= V && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale &&
+      !accumulate && kh * kw <= kThinMaxT && Ho == H + 2 * pad_t - dil * (kh - 1) && Wo == W + 2 * pad_l - dil * (kw - 1) &&
+      pad_t >= 0 && pad_l >= 0 && !getenv("SDHIP_CONV_NO_THIN")) {
+    ThinArgs t;
+    t.x = x; t.wp = wpacked; t.y = y; t.bias = bias; t.stats = stats;
+    t.B = B; t.H = H; t.W = W; t.Ho = Ho; t.Wo = Wo; t.kh = kh; t.kw = kw; t.dil = dil; t.pad_t = pad_t; t.pad_l = pad_l;
+    t.Cin = Cin; t.ldx = ldx; t.ldy = ldy; t.Mpad = a.Mpad; t.act = act; t.bpg = B / groups;
+    t.stats_ld = a.stats_ld; t.nrep = a.nrep; t.rep_stride = a.rep_stride;
+    dim3 grid(sdhip_cdiv(Wo, 256), Ho, B);
+    if (dtype == SDHIP_BF16) hipLaunchKernelGGL(conv_thin_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, t);
+    else hipLaunchKernelGGL(conv_thin_fwd_kernel<float>, grid, dim3(256), 0, s, t);
+    SDHIP_LAUNCH_CHECK();
+    return SDHIP_OK;
+  }
   // ---- fast path (conv_fast.h): 16-byte-aligned pixels on both sides, halo-tile mode ----
   if (!per_tap_any && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && a.vec_out &&
       (long)H * W * ldx < (1L << 31) && !getenv("SDHIP_CONV_GENERIC")) {

@@ -320,8 +320,9 @@ class minidsnetExt(nn.Module):
         both = both8.permute(0, 3, 1, 2)
         img_a = both[:B]
         t = self.resnet_features(both, groups=2)          # taps of both towers, batch = [left | right]
-        a = [u[:B] for u in t]
-        b = [u[B:] for u in t]
+        halves = [ops.split_batch(u, B) for u in t]   # left / right tower outputs (one gradient buffer per tap in the backward)
+        a = [h[0] for h in halves]
+        b = [h[1] for h in halves]
         xl3 = self.conv2d_ba3[0].fused(img_a, act=1)      # computed (and unused) exactly as in the reference
         xl2 = self.conv2d_ba1[0].fused(img_a, act=1)
         xl1 = self.conv2d_ba2[0].fused(img_a, act=1)
@@ -350,7 +351,7 @@ class minidsnetExt(nn.Module):
             s2 = self.aspp(a[1])
         elif self.aspp_mod == 2:
             s2b = self.aspp(t[3], groups=2)
-            s21, s22 = s2b[:B], s2b[B:]
+            s21, s22 = ops.split_batch(s2b, B)
             s2 = ops.concat([torch.squeeze(self.s2_corr_sampler(s21, s22), 1), s21])
         else:
             s2 = ops.concat([a[6], b[6]])
@@ -453,8 +454,9 @@ class dsnet(nn.Module):
         both = both8.permute(0, 3, 1, 2)
         img_a = both[:B]
         t = self.resnet_features(both, groups=2)
-        a = [u[:B] for u in t]
-        b = [u[B:] for u in t]
+        halves = [ops.split_batch(u, B) for u in t]   # left / right tower outputs (one gradient buffer per tap in the backward)
+        a = [h[0] for h in halves]
+        b = [h[1] for h in halves]
         size = (H, W)
         up = ops.interpolate
         xl3 = self.conv2d_ba3[0].fused(img_a, act=1)

@@ -188,7 +188,7 @@ class PSMNet(nn.Module):
         B, _, H, W = left.shape
         both = torch.cat([left, right], 0)
         fea = self.feature_extraction(both, groups=2)        # both towers: one pass, two statistics groups
-        ref, tgt = fea[:B], fea[B:]
+        ref, tgt = ops.split_batch(fea, B)
         D = self.maxdisp // 4
         cost = ops.cost_volume(ref, tgt, D)                   # (B*D, 64, H/4, W/4)
         c0, _ = _run3d(self.dres0[0], cost, D, act=1)

@@ -181,7 +181,7 @@ def main():
                                        "dsnet (PyTorch port of baseline_SDnet_small_fixed, 2-D corr) train step fwd+loss+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s"
                                        if a.model == "dsnet" else
                                        "PSMNet(192) stacked hourglass train step fwd+loss(mean L1 x3)+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s")
-                                      % (a.width, a.height, a.batch, "hipGraph" if not a.no_graph else "eager"),
+                                      % (a.width, a.height, a.batch, "hipGraph" if step.use_graph else "eager"),
                           "global_batch": a.batch * world, "parallelism": "dp%d" % world},
                "loss": round(lossv, 5)}
         sys.stderr.write("[bench] timed region done: %.3f ms/step\n" % (dt / a.steps * 1e3)); sys.stderr.flush()

@@ -125,7 +125,14 @@ class TrainStep:
         if not self.use_graph:
             return self._eager(left, right, seg, disp)
         if self.graph is None:
-            self.capture(left, right, seg, disp)
+            try:
+                self.capture(left, right, seg, disp)
+            except RuntimeError as e:   # e.g. a collective that cannot be captured on this RCCL build: run eagerly, loudly
+                import sys
+                sys.stderr.write("[TrainStep] hipGraph capture failed (%s); continuing WITHOUT a graph\n" % str(e).splitlines()[0])
+                self.graph, self.use_graph = None, False
+                torch.cuda.synchronize()
+                return self._eager(left, right, seg, disp)
         for dst, src in zip(self.static, (left, right, seg, disp)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)

@@ -123,7 +123,7 @@ class _DenseBlockFn(torch.autograd.Function):
                              False, 1, 0, False)
             gw2 = _wgrad(y1, mid, dy2, growth, layer.conv2.weight, B, H, W, mid, growth, 3, 1, sc2, sh2, groups, dt)
             # (3) through relu + norm2's affine, (4) norm2's statistics, (5) into y1
-            if training and ops.parallel.world_size() == 1:
+            if training and ops._fused_bn():
                 dg2, db2 = ops.bn_backward_two_phase(gp2, mid, y1, mid, gp2, mid, sc2, sh2, mu2, iv2, layer.norm2.weight,
                                                      layer.norm2.bias, npix, mid, groups, 1, count, dt)   # in place: elementwise
             else:

@@ -356,6 +356,11 @@ def _bn_finalize(stats, nrep, bn, count, groups, synced=False):
     return out
 
 
+def _fused_bn():
+    """Consumer-side finalize kernels: single-GPU only (the sync-BN exchange sits between reduction and finalize)."""
+    return parallel.world_size() == 1 and not os.environ.get("SDHIP_DIAG_NO_FUSED_BN")
+
+
 def _bn_track(bn, groups):
     """BatchNorm.num_batches_tracked bookkeeping of one train-mode normalisation (see _bn_finalize)."""
     if bn.num_batches_tracked is None:
@@ -570,7 +575,7 @@ class _ConvBNActFn(torch.autograd.Function):
         count = (B // groups) * spec.Ho * spec.Wo
         rv, ldr = nhwc_view(residual) if residual is not None else (None, 0)
         y, ldy = alloc_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
-        if train and parallel.world_size() == 1:
+        if train and _fused_bn():
             # one launch: every workgroup derives scale/shift of its channels from the statistics the conv just wrote
             scale, shift, mean, invstd = [torch.empty((groups, Cout), dtype=torch.float32, device=x.device) for _ in range(4)]
             _bn_track(bn, groups)
@@ -599,7 +604,7 @@ class _ConvBNActFn(torch.autograd.Function):
         g, ldg = nhwc_view(gy)
         graw, ldgr = alloc_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
         ldraw = ctx.ldraw
-        if ctx.train and ctx.act in (0, 1, 2) and parallel.world_size() == 1:
+        if ctx.train and ctx.act in (0, 1, 2) and _fused_bn():
             dgamma, dbeta = bn_backward_two_phase(g, ldg, yraw, ldraw, graw, ldgr, scale, shift, mean, invstd, gamma, beta, npix,
                                                   Cout, groups, ctx.act, ctx.count, dt)
         elif ctx.train and ctx.act in (0, 1, 2):

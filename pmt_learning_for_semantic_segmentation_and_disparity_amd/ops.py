@@ -322,7 +322,9 @@ def _sync_stats(stats, nrep):
     if stats is None or parallel.world_size() == 1:
         return stats, nrep
     G, _, C = stats.shape[-3:]
-    compact = torch.zeros((G, 2, C), dtype=torch.float64, device=stats.device)
+    compact, pz = _zeros((G, 2, C), torch.float64, stats.device)   # zero arena of the step: no fill launch per layer
+    if not pz:
+        compact.zero_()
     call("sdhip_stats_replica_sum", ptr(stats), ptr(compact), nrep, G, C, stats.stride(-2), C, stream_ptr())
     parallel.all_reduce_sum_(compact)
     return compact, 1
@@ -414,7 +416,7 @@ def _bn_backward(gy, ldg, x, ldx, gx, ldgx, scale, shift, mean, invstd, gamma, n
         # sync-BN backward: dgamma/dbeta from the LOCAL sums, the statistics gradient from the GLOBAL sums
         call("sdhip_bn_finalize_bwd", ptr(dsc), ptr(dsh), NREP, ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
              None, C, par_flag, C, groups, float(count), 1, stream_ptr())
-        glob = torch.stack((dsc.sum(0), dsh.sum(0)))          # [2][groups][C]
+        glob = both.sum(1)                                     # [2][groups][C]: one launch folds the replicas of both sums
         parallel.all_reduce_sum_(glob)
         call("sdhip_bn_finalize_bwd", ptr(glob[0]), ptr(glob[1]), 1, ptr(gamma), ptr(mean), ptr(invstd), None, None,
              ptr(dstats), dstats.stride(-2), int(accumulate_dstats), C, groups, float(parallel.global_count(count)), 1,

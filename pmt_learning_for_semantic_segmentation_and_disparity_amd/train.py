@@ -117,7 +117,10 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # data parallel: the RCCL watchdog thread polls events while we capture; thread-local capture errors keep its
+        # (legal) calls from invalidating the capture of this thread
+        mode = "thread_local" if self.world_size > 1 else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss = self._eager(*self.static)
         return self
 

@@ -154,7 +154,6 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     }
   }
   const int mvalid = min(BN, p.Mpad - n0);
-  const int w_rounds = (p.tg * BN + RPR - 1) / RPR;
 
   u32x4 rh[HPF];
   auto slice_of = [&](int qq) { return dz * p.sd + qq / nq - p.pad_d; };

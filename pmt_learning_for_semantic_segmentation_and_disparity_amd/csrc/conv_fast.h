@@ -41,7 +41,9 @@ __device__ __attribute__((aligned(16))) unsigned int sdhip_zero16[4] = {0u, 0u, 
 // prefetch of stage s+1 with the fragment reads of stage s.  The kernel waits for its DMA explicitly before the
 // barrier that publishes a stage instead.
 __device__ __forceinline__ void glds16(const void* g, unsigned lds_wave_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_wave_base) : "memory", "m0");
+  unsigned keep;   // M0 is a register the compiler manages itself: hand it back as found
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_wave_base) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;

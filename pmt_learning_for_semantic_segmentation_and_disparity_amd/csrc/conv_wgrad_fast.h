@@ -380,7 +380,17 @@ int launch_wgf(const WgfArgs& a, hipStream_t s) {
   const double t_tile_us = 0.35 + 0.17 * a.tpb;
   const double flush_us = (double)a.tpb * MB * 64 * 4 / (tune_rate * 1e6);
   int gx = (int)(sqrt((double)ntiles * t_tile_us / flush_us) + 0.5);
-  if (gx > sdhip_cdiv(256, gy)) gx = sdhip_cdiv(256, gy);         // one 8-wave workgroup per CU (registers)
+  // co-resident 8-wave workgroups per CU for this instantiation and LDS size (registers allow two for the 1x1 / narrow
+  // variants): small problems want all their workgroups in flight at once
+  static size_t occ_lds = 0;
+  static int occ = 1;
+  if (occ_lds != lds) {
+    int nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 512, lds) != hipSuccess || nb < 1) nb = 1;
+    occ = nb > 2 ? 2 : nb;
+    occ_lds = lds;
+  }
+  if (gx > sdhip_cdiv(256 * occ, gy)) gx = sdhip_cdiv(256 * occ, gy);
   if (gx > sdhip_cdiv(ntiles, 2)) gx = sdhip_cdiv(ntiles, 2);     // at least two tiles per workgroup: the pipeline overlaps them
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(512), lds, s, a);

@@ -189,7 +189,7 @@ def _zeros(shape, dtype, device):
 def _grad_target(param):
     """The flat-gradient slice to accumulate a parameter gradient into, or None (then the Function returns the gradient)."""
     c = _ctx[0]
-    if c is not None and c.direct_grads and param is not None and param.grad is not None:
+    if c is not None and c.direct_grads and param is not None and param.is_leaf and param.grad is not None:
         return param.grad
     return None
 

@@ -1,0 +1,30 @@
+"""BASELINE.json configs 4 and 5 at their stated sizes: one bf16 training step each (shape / robustness check)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle.ref_models import CFG
+from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N, ops
+from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+
+def run(name, model, B, H, W, labels, pos=False):
+    torch.manual_seed(0)
+    step = TrainStep(model, dtype=torch.bfloat16, use_graph=False)
+    batch = synthetic_batch(B, H, W, labels=labels)
+    if pos:
+        h = (torch.arange(0, H) * 1024 // H).view(1, -1, 1).expand(B, -1, W) // 8
+        w = (torch.arange(0, W) * 2048 // W).view(1, 1, -1).expand(B, H, -1) // 16
+        p = (h.cuda(), w.cuda())
+        fwd = model.forward
+        model.forward = lambda a, b: fwd(a, b, p)
+    for i in range(3):
+        torch.cuda.synchronize(); t0 = time.time()
+        loss = step(*batch)
+        torch.cuda.synchronize()
+        print("%s step %d: loss %.4f  %.1f ms (eager)" % (name, i, float(loss), (time.time() - t0) * 1e3), flush=True)
+    assert torch.isfinite(loss)
+
+run("config5 minidsnetExt(aspp=2,hanet=1,labels=19) 1024x512 B=2",
+    N.minidsnetExt(CFG(dropout=0.0, aspp=2, use_att=1, hanet=1), labels=19, pretrained=False, patch_type='1dcorr').cuda().train(), 2, 512, 1024, 19, pos=True)
+run("config5' minidsnetExt(aspp=0,hanet=1,labels=19) 1024x512 B=2 (HANet on the live branch)",
+    N.minidsnetExt(CFG(dropout=0.0, aspp=0, use_att=1, hanet=1), labels=19, pretrained=False, patch_type='1dcorr').cuda().train(), 2, 512, 1024, 19, pos=True)
+run("config4 dsnet 960x512 B=4", N.dsnet(CFG(), labels=2, pretrained=False).cuda().train(), 4, 512, 960, 2)

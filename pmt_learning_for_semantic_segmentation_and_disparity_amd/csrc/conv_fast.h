@@ -27,6 +27,7 @@ struct FastArgs {
   int D, Do, kd, sd, pad_d;
   int Cin, ldx, Cout, Mpad, ldy;
   int in_relu, bpg, act, accumulate;   // bpg: images per statistics group
+  unsigned magic_iwp;                  // div_magic(halo row pitch) of the chosen tile
   int tg, stats_ld, nrep, tail, dma;   // tail: Cin % (elements per 16 bytes) != 0 -> mask the last chunk; dma: halo by LDS-DMA
   long rep_stride;
 };
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   const int ty = blockIdx.x / tiles_w;
   const int oh0 = ty * TH, ow0 = (blockIdx.x - ty * tiles_w) * TW;
   const int n0 = blockIdx.y * BN;
-  const int b = blockIdx.z / p.Do, dz = blockIdx.z - b * p.Do;
-  const int grp = b / p.bpg;
+  const int b = p.Do == 1 ? (int)blockIdx.z : (int)blockIdx.z / p.Do, dz = blockIdx.z - b * p.Do;
+  const int grp = b < p.bpg ? 0 : b / p.bpg;
   const int IH = (TH - 1) * s + (p.kh - 1) * d + 1, IW = (TW - 1) * s + (p.kw - 1) * d + 1;
   const int IWp = (IW + 7) & ~7;
   const int ih0 = oh0 * s - p.pad_t, iw0 = ow0 * s - p.pad_l;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   const int c_l = (tid & (CH - 1)) ^ (KS == 2 ? (rsub & 6) : ((rsub >> 1) & 2));   // logical chunk this lane fetches
   const int tid16 = tid * 16;
   const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);   // LDS byte address of this wave's KiB in round 0 of smem
-  const unsigned magic_iwp = div_magic(IWp);
+  const unsigned magic_iwp = p.magic_iwp;   // host-computed: a 64-bit division per wave is ~100 instructions of kernel start-up
   constexpr bool dma = DMA;
   const int h_rows = IH * IWp;
   const int h_rounds = (h_rows + RPR - 1) / RPR;
@@ -158,7 +159,10 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   const int mvalid = min(BN, p.Mpad - n0);
 
   u32x4 rh[HPF];
-  auto slice_of = [&](int qq) { return dz * p.sd + qq / nq - p.pad_d; };
+  // chunk qq = (depth tap, channel chunk); plain 2-D convolutions (kd == 1) skip the scalar divisions
+  const bool flat = p.kd == 1;
+  auto chunk_of = [&](int qq) { return flat ? qq : qq % nq; };
+  auto slice_of = [&](int qq) { return flat ? dz * p.sd - p.pad_d : dz * p.sd + qq / nq - p.pad_d; };
 
   auto mask_tail = [&](u32x4 raw, int ch0) -> u32x4 {   // zero the elements at channel >= Cin (rare: odd channel counts)
     const int nv = p.Cin - ch0;
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
 
   // small tiles: issue the whole halo tile of chunk qq (DMA: straight into `dst`; register path: into rh[])
   auto halo_issue = [&](int qq, unsigned char* dst) {
-    const int q = qq % nq;
+    const int q = chunk_of(qq);
     const int din = slice_of(qq);
     const bool ok = din >= 0 && din < p.D && q * CKS + c_l * V < p.Cin;
     const T* xb = xb0 + (long)din * p.H * p.W * p.ldx + q * CKS;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     }
   };
   auto halo_commit = [&](int qq, unsigned char* dst) {   // register path only
-    const int ch0 = (qq % nq) * CKS + c_l * V;
+    const int ch0 = chunk_of(qq) * CKS + c_l * V;
     const int din = slice_of(qq);
     const bool ok = din >= 0 && din < p.D && ch0 < p.Cin;
     if (p.in_scale) prologue_load(ch0);
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   };
   // large tiles: stage the whole halo tile now (DMA: every round in flight at once; register path: 4 rounds at a time)
   auto halo_sync_stage = [&](int qq, unsigned char* dst) {
-    const int ch0 = (qq % nq) * CKS + c_l * V;
+    const int ch0 = chunk_of(qq) * CKS + c_l * V;
     const int din = slice_of(qq);
     const bool ok = din >= 0 && din < p.D && ch0 < p.Cin;
     const T* xb = xb0 + (long)din * p.H * p.W * p.ldx + ch0;

@@ -522,6 +522,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
       if (lds < 4096) lds = 4096;
       if (lds > kMax) { if (!fbig) break; fbig = false; continue; }
       f.tg = tg;
+      f.magic_iwp = IWp > 1 ? (unsigned)(0x100000000ULL / (unsigned)IWp) + 1u : 0u;
       return dtype == SDHIP_BF16 ? launch_fast_any<bf16_t>(f, fbig, ks, bn, lds, s) : launch_fast_any<float>(f, fbig, ks, bn, lds, s);
     }
   }

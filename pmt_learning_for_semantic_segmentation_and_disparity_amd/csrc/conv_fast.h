@@ -27,7 +27,8 @@ struct FastArgs {
   int D, Do, kd, sd, pad_d;
   int Cin, ldx, Cout, Mpad, ldy;
   int in_relu, bpg, act, accumulate;   // bpg: images per statistics group
-  unsigned magic_iwp;                  // div_magic(halo row pitch) of the chosen tile
+  unsigned magic_iwp, magic_tw;        // div_magic(halo row pitch), div_magic(tiles per output row) of the chosen tile
+  int tiles_w, ntg;                    // tiles per output row, tap groups per chunk
   int tg, stats_ld, nrep, tail, dma;   // tail: Cin % (elements per 16 bytes) != 0 -> mask the last chunk; dma: halo by LDS-DMA
   long rep_stride;
 };
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int s = p.stride, d = p.dil;
-  const int tiles_w = (p.Wo + TW - 1) / TW;
-  const int ty = blockIdx.x / tiles_w;
+  const int tiles_w = p.tiles_w;
+  const int ty = fast_div(blockIdx.x, tiles_w, p.magic_tw);   // < 2^16 tiles per image (host-checked)
   const int oh0 = ty * TH, ow0 = (blockIdx.x - ty * tiles_w) * TW;
   const int n0 = blockIdx.y * BN;
   const int b = p.Do == 1 ? (int)blockIdx.z : (int)blockIdx.z / p.Do, dz = blockIdx.z - b * p.Do;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
 
   const T* const xb0 = (const T*)p.x + (long)b * p.D * p.H * p.W * p.ldx;
   const T* const wpk = (const T*)p.wp;
-  const int ntg = (Tn + p.tg - 1) / p.tg;
+  const int ntg = p.ntg;
 
   // ---- fragment addressing: everything per lane is computed once ----
   // wave's pixel tiles: pt = wave*NT_PIX + ni -> tile row pt / TWT, column block pt % TWT.  Row pitch IWp and the

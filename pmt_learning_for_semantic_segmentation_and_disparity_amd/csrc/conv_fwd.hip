@@ -523,6 +523,10 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
       if (lds > kMax) { if (!fbig) break; fbig = false; continue; }
       f.tg = tg;
       f.magic_iwp = IWp > 1 ? (unsigned)(0x100000000ULL / (unsigned)IWp) + 1u : 0u;
+      f.tiles_w = sdhip_cdiv(Wo, tw);
+      f.magic_tw = f.tiles_w > 1 ? (unsigned)(0x100000000ULL / (unsigned)f.tiles_w) + 1u : 0u;
+      f.ntg = sdhip_cdiv(T, tg);
+      if ((long)f.tiles_w * sdhip_cdiv(Ho, th) >= 65536) break;   // fast_div range: general kernel for gigantic images
       return dtype == SDHIP_BF16 ? launch_fast_any<bf16_t>(f, fbig, ks, bn, lds, s) : launch_fast_any<float>(f, fbig, ks, bn, lds, s);
     }
   }

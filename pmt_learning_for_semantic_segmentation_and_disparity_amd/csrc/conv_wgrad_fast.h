@@ -118,15 +118,20 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   const int krows = (32 / TW) * s * IWp;
   const int cx = ((ci_tile * 16) >> 3) + (p4 >> 1);
   int b_lo[MAXTW], b_hi[MAXTW];
+  {
+    // taps t0 + tap_lane, + TAPL, ...: one division for the first, then a carry walk (kernel start-up is on the critical
+    // path of the many tiny launches)
+    int khi = (t0 + tap_lane) / p.kw, kwi = (t0 + tap_lane) - khi * p.kw;
+    const int row_first = lrow + ((t0 / p.kw) * d) * IWp + (t0 % p.kw) * d;   // tap t0: what idle slots read
 #pragma unroll
-  for (int tl = 0; tl < MAXTW; ++tl) {
-    int tt = tl * TAPL + tap_lane;
-    if (tt >= nt) tt = 0;                    // idle slot: reads tap 0, result never flushed
-    const int t = t0 + tt;
-    const int khi = t / p.kw, kwi = t - khi * p.kw;
-    const int row = lrow + (khi * d) * IWp + kwi * d;
-    b_lo[tl] = WRow::off(row, cx) + sub;
-    b_hi[tl] = WRow::off(row + 4 * s, cx) + sub;
+    for (int tl = 0; tl < MAXTW; ++tl) {
+      const int tt = tl * TAPL + tap_lane;
+      const int row = tt < nt ? lrow + (khi * d) * IWp + kwi * d : row_first;   // idle slot: result never flushed
+      b_lo[tl] = WRow::off(row, cx) + sub;
+      b_hi[tl] = WRow::off(row + 4 * s, cx) + sub;
+      kwi += TAPL;
+      while (kwi >= p.kw) { kwi -= p.kw; ++khi; }
+    }
   }
 
   // ---- staging (linear LDS destination, swizzled source: see conv_fast.h) ----

@@ -24,6 +24,7 @@ namespace {
 struct RowGeom {  // how a 256-thread block walks a [npix][C] matrix
   int tx, ty;     // threads across channel units / across pixels
   int units;      // channel units per row (16-byte chunks, or single elements in scalar mode)
+  unsigned magic; // div_magic(tx): thread -> (tx, ty) without an integer division per lane (these kernels are often ~5 us)
 };
 
 inline RowGeom row_geom(int units) {
@@ -31,8 +32,13 @@ inline RowGeom row_geom(int units) {
   r.units = units;
   r.tx = units < 64 ? units : 64;
   r.ty = 256 / r.tx;
+  r.magic = r.tx > 1 ? (unsigned)(0x100000000ULL / (unsigned)r.tx) + 1u : 0u;
   return r;
 }
+
+// threadIdx.x -> ty = tid / tx (tid < 256: exact with the 2^32/tx + 1 magic), tx = tid - ty * tx
+#define ROW_TXTY(rg, tx, ty) const int ty = (rg).tx > 1 ? (int)__umulhi((unsigned)threadIdx.x, (rg).magic) : (int)threadIdx.x; \
+                             const int tx = (int)threadIdx.x - ty * (rg).tx
 
 // y = act(x*scale + shift) (+ res);  grid: (pixel slabs, unit groups, stat groups)
 template <typename T, bool VEC>
@@ -41,7 +47,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          int C, long npix_g, int act, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
-  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  ROW_TXTY(rg, tx, ty);
   const int u = blockIdx.y * rg.tx + tx;
   if (ty >= rg.ty || u >= rg.units) return;
   const int g = blockIdx.z, c0 = u * N;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* gy, int ld
                                                              int C, long npix_g, int act, int accumulate, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
   __shared__ float red[2][256 * (VEC ? Chunk<T>::N : 1)];
-  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  ROW_TXTY(rg, tx, ty);
   const int u = blockIdx.y * rg.tx + tx;
   const bool live = ty < rg.ty && u < rg.units;
   const int g = blockIdx.z, c0 = u * N;
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const T* gin, int ldgi, 
                                                         T* gout, int ldgo, const double* __restrict__ dS, int ldc,
                                                         int C, long npix_g, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
-  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  ROW_TXTY(rg, tx, ty);
   const int u = blockIdx.y * rg.tx + tx;
   if (ty >= rg.ty || u >= rg.units) return;
   const int g = blockIdx.z, c0 = u * N;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ shift, const double* __restrict__ dS, int ldc,
                                                            int C, long npix_g, int act, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
-  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  ROW_TXTY(rg, tx, ty);
   const int u = blockIdx.y * rg.tx + tx;
   if (ty >= rg.ty || u >= rg.units) return;
   const int g = blockIdx.z, c0 = u * N;
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) void affine_act_bn_kernel(const T* __restrict_
     if (writer && rl == 0 && okc) { rmean[c] = rm; rvar[c] = rv; }
   }
   __syncthreads();
-  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  ROW_TXTY(rg, tx, ty);
   const int u = blockIdx.y * rg.tx + tx;
   if (ty >= rg.ty || u >= rg.units) return;
   const int c0 = u * N;
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* gy, int 
     }
   }
   __syncthreads();
-  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  ROW_TXTY(rg, tx, ty);
   const int u = blockIdx.y * rg.tx + tx;
   if (ty >= rg.ty || u >= rg.units) return;
   const int c0 = u * N;
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
                                                             int C, long npix_g, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
   __shared__ float red[2][256 * (VEC ? Chunk<T>::N : 1)];
-  const int tx = threadIdx.x % rg.tx, ty = threadIdx.x / rg.tx;
+  ROW_TXTY(rg, tx, ty);
   const int u = blockIdx.y * rg.tx + tx;
   const bool live = ty < rg.ty && u < rg.units;
   const int g = blockIdx.z, c0 = u * N;

@@ -300,6 +300,31 @@ int sdhip_mul_rows_bwd(const void* g, int ldg, const void* a, int lda, const voi
 int sdhip_dropout_channels(const void* x, int ldx, void* y, int ldy, const long* seed, long layer_id, int B, int L, int C,
                            float p, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * On-device step metrics: one pass over the step's outputs replaces the host-side block
+ * of losses/multiLosses.py:116-125,146-154 — SegAccuracyNp (util/utilTorchLoss.py:221-236), GetSegMetricsNp
+ * (:251-303), unnormalizedErrorNP (:363-370) and GetDispMetricsNp (:318-343) — which copies three full-resolution
+ * maps to the host and runs numpy / sklearn on them every step.
+ *   seg         (B*hw pixels, L logits, pixel stride lds) of `dtype`, or NULL
+ *   seg_target  one-hot f32, Ct = L or L+1 channels (channel L = "ignore", mask `gt_seg != labels`), pixel stride ldt
+ *   disp        dense B*hw disparities of `dtype`, or NULL;  disp_target dense f32
+ *   mask_invalid  1: multiply prediction and target by (target > 0) first (`zeros` of lossDisp_fn for kitti/cityscapes)
+ * ACCUMULATES (the caller zeroes once per reporting interval) into
+ *   counts[0 .. L*L)   confusion matrix, counts[L*gt + pred] over the pixels whose gt class != L
+ *   counts[L*L + k], k < SDHIP_METRIC_COUNTS:
+ *     0..3  image 0: TP, FP, FN, TN of (logit[1] > 0) against target[1]   (precision / recall / f1, average="micro")
+ *     4,5   image 0: matching values and size of the branch mask (target[1] == 1 or raw logit[1] == 1)   (Bf1)
+ *     6,7   whole batch: #(|pred - gt| * max_disp > 3 and gt > 0), #(gt > 0)                          (err, val_pxl)
+ *     8     image 0: #(target[1] == 1)
+ *   sums[k], k < SDHIP_METRIC_SUMS (f64): image 0: sum (gt-pred)^2, sum (gt-pred)^2/gt, and the same two over the
+ *     pixels with target[1] == 1 (dispRMSE, dispSqRel, branch variants).
+ * ------------------------------------------------------------------------- */
+#define SDHIP_METRIC_COUNTS 9
+#define SDHIP_METRIC_SUMS 4
+int sdhip_step_metrics(const void* seg, int lds, const float* seg_target, int ldt, int Ct, const void* disp,
+                       const float* disp_target, long* counts, double* sums, int B, long hw, int L, float max_disp,
+                       int mask_invalid, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,7 @@ def _install_stubs():
         sys.modules.setdefault(name, types.ModuleType(name))
     for sub in ("models", "transforms", "datasets"):
         setattr(sys.modules["torchvision"], sub, sys.modules["torchvision." + sub])
+    sys.modules["cv2"].imwrite = lambda *a, **k: True   # GetSegMetricsNp / GetDispMetricsNp dump JPEGs; not part of the results
     eff = types.ModuleType("efficientnet_pytorch")
     eff.EfficientNet = type("EfficientNet", (), {})
     sys.modules["efficientnet_pytorch"] = eff
@@ -274,6 +275,41 @@ def gen_hanet():
     save("hanet", **arrays)
 
 
+def gen_metrics():
+    """The host-side step metrics of lossSeg_fn / lossDisp_fn (losses/multiLosses.py:116-125,146-154), produced by the
+    reference's own numpy / sklearn functions.  Inputs are stored (they are small)."""
+    import warnings
+    from util import utilTorchLoss as UL
+    rng = np.random.default_rng(7)
+    arrays = {}
+    cases = [("roses", 2, 2, 2, 24, 40, 1.0, False), ("city", 19, 20, 2, 16, 24, 192.0, True), ("one", 2, 2, 1, 8, 8, 1.0, False)]
+    for name, L, Ct, B, H, W, max_disp, mask_invalid in cases:
+        logits = rng.normal(0, 2, (B, L, H, W)).astype(np.float32)
+        logits[0, 1, 0, :4] = [0.0, 1.0, -1.0, 1.0]                        # exact 0 / 1 logits exercise the threshold and branch-mask rules
+        cls = rng.integers(0, Ct, (B, H, W))
+        seg_full = np.eye(Ct, dtype=np.float32)[cls].transpose(0, 3, 1, 2).copy()
+        disp = (rng.uniform(0, 8, (B, 1, H, W)) * (rng.uniform(0, 1, (B, 1, H, W)) > (0.3 if mask_invalid else -1))).astype(np.float32)
+        if not mask_invalid:
+            disp += np.float32(0.1)
+        disp_pred = (disp + rng.normal(0, 1.5 / max_disp ** 0.5, disp.shape)).astype(np.float32)
+        logsm = F.log_softmax(torch.from_numpy(logits), 1).numpy()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            acc, conf, _ = UL.SegAccuracyNp(logsm, seg_full, L)
+            prec, rec, f1, bf1 = UL.GetSegMetricsNp(logits.copy(), seg_full.copy(), L, num_image=0)
+            zeros = (disp > 0) * np.float32(1.0) if mask_invalid else 1.0     # multiLosses.py:134-139,146-148
+            dp, dg = disp_pred * zeros, disp * zeros
+            err, val = UL.unnormalizedErrorNP(dp, dg, max_disp)
+            rmse, sqrel, brmse, bsqrel = UL.GetDispMetricsNp(dp.copy(), dg.copy(), seg_full, num_image=0)
+        arrays.update(flat(name, dict(logits=logits, seg_full=seg_full, disp=disp, disp_pred=disp_pred, labels=np.int64(L),
+                                      max_disp=np.float64(max_disp), mask_invalid=np.int64(mask_invalid),
+                                      pixelAcc=np.float64(acc), conf_matrix=conf.astype(np.int64), pixelPrec=np.float64(prec),
+                                      pixelRecall=np.float64(rec), pixelF1=np.float64(f1), pixelBF1=np.float64(bf1),
+                                      err=np.float64(err), val_pxl=np.float64(val), dispRMSE=np.float64(rmse),
+                                      dispSqRel=np.float64(sqrel), BdispRMSE=np.float64(brmse), BdispSqRel=np.float64(bsqrel))))
+    save("metrics", **arrays)
+
+
 def gen_dsnet():
     from models import dsnet_t2 as D
     arrays = {}
@@ -339,7 +375,7 @@ if __name__ == "__main__":
     _install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet", "hanet"]
+    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet", "hanet", "metrics"]
     if "ops" in which:
         gen_ops()
     if "backbone" in which:
@@ -352,3 +388,5 @@ if __name__ == "__main__":
         gen_dsnet()
     if "hanet" in which:
         gen_hanet()
+    if "metrics" in which:
+        gen_metrics()

@@ -309,7 +309,9 @@ int sdhip_dropout_channels(const void* x, int ldx, void* y, int ldy, const long*
  *   seg_target  one-hot f32, Ct = L or L+1 channels (channel L = "ignore", mask `gt_seg != labels`), pixel stride ldt
  *   disp        dense B*hw disparities of `dtype`, or NULL;  disp_target dense f32
  *   mask_invalid  1: multiply prediction and target by (target > 0) first (`zeros` of lossDisp_fn for kitti/cityscapes)
- * ACCUMULATES (the caller zeroes once per reporting interval) into
+ * ACCUMULATES (the caller zeroes once per reporting interval) into `nrep` replicas — workgroup g adds into replica
+ * g % nrep, so that the closing atomics do not all serialise on one cache line; the caller sums the replicas.  Replica r
+ * starts at counts + r*rep_stride (rep_stride >= L*L + SDHIP_METRIC_COUNTS) and sums + r*SDHIP_METRIC_SUM_STRIDE:
  *   counts[0 .. L*L)   confusion matrix, counts[L*gt + pred] over the pixels whose gt class != L
  *   counts[L*L + k], k < SDHIP_METRIC_COUNTS:
  *     0..3  image 0: TP, FP, FN, TN of (logit[1] > 0) against target[1]   (precision / recall / f1, average="micro")
@@ -321,9 +323,10 @@ int sdhip_dropout_channels(const void* x, int ldx, void* y, int ldy, const long*
  * ------------------------------------------------------------------------- */
 #define SDHIP_METRIC_COUNTS 9
 #define SDHIP_METRIC_SUMS 4
+#define SDHIP_METRIC_SUM_STRIDE 32   /* doubles per replica of `sums` (one 256-byte line) */
 int sdhip_step_metrics(const void* seg, int lds, const float* seg_target, int ldt, int Ct, const void* disp,
-                       const float* disp_target, long* counts, double* sums, int B, long hw, int L, float max_disp,
-                       int mask_invalid, int dtype, void* stream);
+                       const float* disp_target, long* counts, double* sums, int nrep, int rep_stride, int B, long hw,
+                       int L, float max_disp, int mask_invalid, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

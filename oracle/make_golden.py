@@ -310,6 +310,31 @@ def gen_metrics():
     save("metrics", **arrays)
 
 
+def gen_keys():
+    """Ordered state_dict keys (+shapes) and ordered parameter names of the reference's networks: the checkpoint surface
+    (`state_dict` keys, and torch.optim.Adam state indexed by parameter order — torch_implementation.py:915-934)."""
+    import importlib
+    import json
+    from models import dsnet_t2 as D
+    SH = importlib.import_module("models_psmnet.stackhourglass")
+    nets = {
+        "mini_a0": lambda: D.minidsnetExt(R.CFG(aspp=0), labels=2, pretrained=False, patch_type='1dcorr', backbone='densenet'),
+        "mini_a1": lambda: D.minidsnetExt(R.CFG(aspp=1), labels=2, pretrained=False, patch_type='1dcorr', backbone='densenet'),
+        "mini_a2_hanet": lambda: D.minidsnetExt(R.CFG(aspp=2, hanet=1), labels=19, pretrained=False, patch_type='1dcorr', backbone='densenet'),
+        "dsnet": lambda: D.dsnet(R.CFG(), labels=2, pretrained=False),
+        "psmnet192": lambda: SH.PSMNet(192),
+    }
+    out = {}
+    for name, ctor in nets.items():
+        m = ctor()
+        out[name] = {"state_dict": [[k, list(v.shape)] for k, v in m.state_dict().items()],
+                     "parameters": [k for k, _ in m.named_parameters()]}
+        print(name, len(out[name]["state_dict"]), "keys,", len(out[name]["parameters"]), "parameters")
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "keys.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+
+
 def gen_dsnet():
     from models import dsnet_t2 as D
     arrays = {}
@@ -375,7 +400,7 @@ if __name__ == "__main__":
     _install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet", "hanet", "metrics"]
+    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet", "hanet", "metrics", "keys"]
     if "ops" in which:
         gen_ops()
     if "backbone" in which:
@@ -390,3 +415,5 @@ if __name__ == "__main__":
         gen_hanet()
     if "metrics" in which:
         gen_metrics()
+    if "keys" in which:
+        gen_keys()

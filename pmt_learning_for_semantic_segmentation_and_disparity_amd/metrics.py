@@ -20,7 +20,8 @@ from . import _lib
 from ._lib import call, dtype_code, ptr, stream_ptr
 from .ops import _require_gpu, nhwc_view
 
-N_COUNTS, N_SUMS = 9, 4      # SDHIP_METRIC_COUNTS / SDHIP_METRIC_SUMS of include/sdhip.h
+N_COUNTS, N_SUMS, SUM_STRIDE = 9, 4, 32      # SDHIP_METRIC_COUNTS / _SUMS / _SUM_STRIDE of include/sdhip.h
+NREP = 32                                    # replicas the workgroups spread their closing atomics over
 
 
 def _safe_div(a, b):
@@ -40,8 +41,9 @@ class StepMetrics:
         if not torch.cuda.is_available():
             raise _lib.SdhipError("StepMetrics needs a GPU; there is no CPU path")
         self.labels, self.max_disp, self.mask_invalid = int(labels), float(max_disp), bool(mask_invalid)
-        self.counts = torch.zeros(self.labels ** 2 + N_COUNTS, dtype=torch.int64, device=device)
-        self.sums = torch.zeros(N_SUMS, dtype=torch.float64, device=device)
+        self.rep_stride = ((self.labels ** 2 + N_COUNTS + 31) // 32) * 32       # whole 256-byte lines per replica
+        self.counts = torch.zeros(NREP, self.rep_stride, dtype=torch.int64, device=device)
+        self.sums = torch.zeros(NREP, SUM_STRIDE, dtype=torch.float64, device=device)
         self.first_pixels = 0      # pixels of "image 0" seen (for the means of GetDispMetricsNp)
         self.seg_pixels = 0
 
@@ -84,12 +86,16 @@ class StepMetrics:
             gv = disp.contiguous()
         call("sdhip_step_metrics", ptr(sv) if sv is not None else None, lds, ptr(tv) if tv is not None else None, ldt, Ct,
              ptr(dv) if dv is not None else None, ptr(gv) if gv is not None else None, ptr(self.counts), ptr(self.sums),
-             B, H * W, self.labels, self.max_disp, int(self.mask_invalid), dt, stream_ptr())
+             NREP, self.rep_stride, B, H * W, self.labels, self.max_disp, int(self.mask_invalid), dt, stream_ptr())
         self._keep = (sv, tv, dv, gv)          # alive until the next call (the launch is asynchronous)
         if disp_pred is not None:
             self.first_pixels += H * W
         if seg_pred is not None:
             self.seg_pixels += H * W
+
+    def totals(self):
+        """(counts[L*L + N_COUNTS] int64, sums[N_SUMS] f64) on the device, replicas summed."""
+        return self.counts.sum(0)[:self.labels ** 2 + N_COUNTS], self.sums.sum(0)[:N_SUMS]
 
     def compute(self):
         """One device->host copy; returns a dict with the reference's names.
@@ -103,8 +109,8 @@ class StepMetrics:
                                                      name promises is reported as BdispRMSE_masked
         """
         L = self.labels
-        c = self.counts.cpu().numpy()
-        s = self.sums.cpu().numpy()
+        c = self.totals()[0].cpu().numpy()
+        s = self.sums.sum(0)[:N_SUMS].cpu().numpy()
         conf = c[:L * L].reshape(L, L).copy()
         k = c[L * L:]
         tp, fp, fn = int(k[0]), int(k[1]), int(k[2])

@@ -115,8 +115,8 @@ def test_hip_metrics_padded_stride_and_partial_calls():
         assert _same(a[k], want[k]) and _same(b[k], a[k]), (k, a[k], b[k], want[k])
     m3, _ = _gpu_metrics(logits, seg_full, dp, dg, 2, 1.0, False, repeat=3)
     m1, _ = _gpu_metrics(logits, seg_full, dp, dg, 2, 1.0, False)
-    assert torch.equal(m3.counts, 3 * m1.counts)
-    assert torch.allclose(m3.sums, 3 * m1.sums, rtol=1e-12)
+    assert torch.equal(m3.totals()[0], 3 * m1.totals()[0])
+    assert torch.allclose(m3.totals()[1], 3 * m1.totals()[1], rtol=1e-12)
 
 
 @pytest.mark.gpu
@@ -139,7 +139,7 @@ def test_hip_metrics_full_size_properties():
     assert conf.sum() == B * H * W
     np.testing.assert_array_equal(conf.sum(1), torch.bincount(cls.flatten(), minlength=L).cpu().numpy())
     np.testing.assert_array_equal(conf.sum(0), torch.bincount(logits.float().argmax(1).flatten(), minlength=L).cpu().numpy())
-    k = m.counts[L * L:].cpu().numpy()
+    k = m.totals()[0][L * L:].cpu().numpy()
     assert k[0] + k[1] + k[2] + k[3] == H * W and k[7] == B * H * W
     d = (disp[0, 0] - dp[0, 0].float())
     assert abs(out["dispRMSE"] - float(d.double().pow(2).mean().sqrt())) < 1e-6

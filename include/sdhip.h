@@ -328,6 +328,40 @@ int sdhip_step_metrics(const void* seg, int lds, const float* seg_target, int ld
                        const float* disp_target, long* counts, double* sums, int nrep, int rep_stride, int B, long hw,
                        int L, float max_disp, int mask_invalid, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * On-device sample preparation: everything CustomDataset.__getitem__ does after the PNG
+ * containers are decoded (util/utilTorchDataLoader.py:133-274) — PFM decode + flipud (util/utilIOPfm.py:66-101),
+ * depth -> disparity (:173-181), output activation (:188-197), one-hot target (:199-211; cityscapes table
+ * util/utilCityscape.py:173-186), crop window (RandomCrop :435-463), (x/255 - mean)/std in float64 (:247-248) and the
+ * HWC -> tensor conversion of ToTensor (:608-630) — in one launch per sample, writing one batch slot.
+ *   left,right  uint8 H x W x img_cs (first 3 channels used), row pitch img_pitch bytes          -> out_left/out_right:
+ *               out_h x out_w pixels of `dtype`, pixel stride ld_img (>= 3), value ((v/255 - mean[c]) / std[c])
+ *   seg         uint8 H x W x seg_cs; channel seg_channel is classified by seg_mode:
+ *               SDHIP_SEG_THRESHOLD (roses: class = v > seg_threshold), SDHIP_SEG_ID_PLUS_ONE (garden: class = v - 1),
+ *               SDHIP_SEG_LUT (class = lut[v], a 256-byte device table; 255 there must already be mapped to n_seg - 1)
+ *               -> out_seg f32 one-hot, n_seg channels, pixel stride ld_seg
+ *   depth       SDHIP_DEPTH_PFM: the PFM payload (f32 rows, bottom row first, depth_pitch bytes apart, byte-swapped when
+ *               depth_big_endian): disparity = depth > 0 ? fb / depth : 0;  SDHIP_DEPTH_U16: uint16 rows, disparity = v/256
+ *               then activation: LINEAR none; SIGMOID min(d,max_d)/max_d; TANH d' = min(d,max_d), d' != 0 ? 2d'/max_d-1 : -1
+ *               -> out_disp f32 dense out_h x out_w
+ * Any of the three groups may be NULL.  All pointers are device pointers; mean/std are HOST float[3].
+ * ------------------------------------------------------------------------- */
+#define SDHIP_SEG_THRESHOLD 0
+#define SDHIP_SEG_ID_PLUS_ONE 1
+#define SDHIP_SEG_LUT 2
+#define SDHIP_DEPTH_PFM 0
+#define SDHIP_DEPTH_U16 1
+#define SDHIP_ACT_LINEAR 0
+#define SDHIP_ACT_SIGMOID 1
+#define SDHIP_ACT_TANH 2
+int sdhip_prepare_sample(const unsigned char* left, const unsigned char* right, long img_pitch, int img_cs,
+                         const unsigned char* seg, long seg_pitch, int seg_cs, int seg_channel, int seg_mode,
+                         int seg_threshold, const unsigned char* lut, const void* depth, long depth_pitch,
+                         int depth_mode, int depth_big_endian, int H, int W, int crop_top, int crop_left,
+                         int out_h, int out_w, float fb, float max_d, int activation, const float* mean,
+                         const float* stdv, void* out_left, void* out_right, int ld_img, float* out_seg,
+                         int ld_seg, int n_seg, float* out_disp, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

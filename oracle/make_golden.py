@@ -335,6 +335,104 @@ def gen_keys():
         json.dump(out, f, separators=(",", ":"))
 
 
+def _install_loader_stubs():
+    """util/utilTorchDataLoader.py imports skimage / cv2 / torchvision at module level; none is installed here.  The
+    fixture only covers what happens AFTER the containers are decoded, so the two decoders it calls are routed to PIL
+    (`skimage.io.imread`, `cv2.imread(path, -1)`), and the Sobel edge map (an output this build does not produce,
+    `-edges 0`) is a zero map.  Nothing else from these packages runs on the path."""
+    from PIL import Image
+    sk = types.ModuleType("skimage")
+    for sub in ("io", "transform", "filters", "measure", "color", "morphology"):
+        m = types.ModuleType("skimage." + sub)
+        sys.modules["skimage." + sub] = m
+        setattr(sk, sub, m)
+    sys.modules["skimage"] = sk
+    sk.io.imread = lambda path: np.asarray(Image.open(path))
+    sk.filters.sobel = lambda img: np.zeros(np.asarray(img).shape[:2], dtype=np.float64)
+    sk.measure.label = sk.color.rgb2gray = sk.morphology.dilation = sk.morphology.square = lambda *a, **k: a[0]
+    sys.modules["cv2"].imread = lambda path, flag=-1: np.asarray(Image.open(path))
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    sys.modules["torchvision.transforms.functional"] = tvf
+    sys.modules["torchvision.transforms"].functional = tvf
+    sys.modules["torchvision.transforms"].Compose = lambda ts: (lambda s: [s := t(s) for t in ts][-1])
+
+
+def _write_pfm(path, img, little=True):
+    """Grey PFM as the format defines it (rows bottom-up); both byte orders, which readPFM accepts (utilIOPfm.py:89-93)."""
+    h, w = img.shape
+    with open(path, "wb") as f:
+        f.write(b"Pf\n%d %d\n%s\n" % (w, h, b"-1.000000" if little else b"1.000000"))
+        f.write(np.flipud(img).astype("<f4" if little else ">f4").tobytes())
+
+
+def gen_data():
+    """Samples produced by the reference's own CustomDataset.__getitem__ / RandomCrop / ToTensor / readPFM
+    (util/utilTorchDataLoader.py, util/utilIOPfm.py) from synthetic files; inputs are stored raw."""
+    import tempfile
+    from PIL import Image
+    _install_loader_stubs()
+    from util import utilTorchDataLoader as DL
+    from util.utilCityscape import id2label
+    rng = np.random.default_rng(11)
+    arrays = {}
+    H, W = 24, 40
+    tmp = tempfile.mkdtemp(prefix="sdhip_golden_")
+    cases = [("roses_linear", "roses", 2, 192, "linear", (0, 0), True, ((0., 0., 0.), (1., 1., 1.))),
+             ("roses_crop", "roses", 2, 192, "linear", (16, 24), True, ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))),
+             ("roses_sigmoid_be", "roses", 2, 12, "sigmoid", (0, 0), False, ((0., 0., 0.), (1., 1., 1.))),
+             ("garden_tanh", "garden", 9, 12, "tanh", (16, 32), True, ((0., 0., 0.), (1., 1., 1.))),
+             ("city_linear", "cityscapes", 19, 192, "linear", (16, 24), True, ((0., 0., 0.), (1., 1., 1.)))]
+    for name, ds, n_labels, max_d, act, crop, little, norm in cases:
+        left = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        right = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        if ds == "roses":
+            seg = rng.choice(np.array([0, 127, 128, 129, 255], dtype=np.uint8), (H, W, 3))
+        elif ds == "garden":
+            seg = rng.integers(0, n_labels + 2, (H, W), dtype=np.uint8)          # 0 and n_labels+1 are in no class
+        else:
+            seg = rng.integers(0, 34, (H, W), dtype=np.uint8)
+        inst = rng.integers(0, 4, (H, W), dtype=np.uint8)
+        p = lambda f: os.path.join(tmp, name + "_" + f)
+        Image.fromarray(left).save(p("l.png")); Image.fromarray(right).save(p("r.png"))
+        Image.fromarray(seg).save(p("s.png")); Image.fromarray(inst).save(p("i.png"))
+        if ds in ("roses", "garden"):
+            depth = rng.uniform(0.5, 40, (H, W)).astype(np.float32)
+            depth[rng.uniform(size=(H, W)) < 0.1] = 0.0
+            depth[rng.uniform(size=(H, W)) < 0.05] = -1.0
+            depth[0, 0], depth[0, 1] = np.nan, np.inf
+            _write_pfm(p("d.pfm"), depth, little)
+            dpath = p("d.pfm")
+            arrays[name + ".depth_file"] = np.frombuffer(open(dpath, "rb").read(), dtype=np.uint8)
+        else:
+            d16 = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+            d16[rng.uniform(size=(H, W)) < 0.2] = 0
+            Image.fromarray(d16).save(p("d.png"))
+            dpath = p("d.png")
+            arrays[name + ".depth_u16"] = d16
+        normalize = np.array(norm, dtype=np.float32)
+        tf = DL.RandomCrop(list(crop), datasetName=ds, is_down=False, sliceandSwitch=False, augment_DoubleLeftImg=False,
+                           focusPerson=False, resizeImg=False, flipHorizontal=False)
+        dset = DL.CustomDataset([(p("l.png"), p("r.png"))], [(dpath, p("s.png"), p("i.png"))], n_labels, max_d, ds, normalize,
+                                output_activation=act, transform=tf, to_tensor=DL.ToTensor())
+        torch.manual_seed(123)
+        s = dset[0]
+        arrays.update(flat(name, dict(left_u8=left, right_u8=right, seg_u8=seg, n_labels=np.int64(n_labels), max_d=np.float64(max_d),
+                                      crop=np.array(crop, dtype=np.int64), normalize=normalize, seed=np.int64(123),
+                                      left=s["left"].numpy(), right=s["right"].numpy(), seg=s["seg"].numpy().astype(np.float32),
+                                      disp=s["disp"].numpy().astype(np.float32))))
+        arrays[name + ".dataset"] = np.array(ds)
+        arrays[name + ".activation"] = np.array(act)
+        print(name, {k: tuple(v.shape) for k, v in s.items() if hasattr(v, "shape")}, s["disp"].dtype, s["seg"].dtype)
+    lut = np.full(256, 255, dtype=np.int64)
+    for i, lab in id2label.items():
+        if 0 <= i < 256:
+            lut[i] = lab.trainId
+    arrays["cityscapes.id2trainId"] = lut
+    save("data", **arrays)
+    import shutil
+    shutil.rmtree(tmp)
+
+
 def gen_dsnet():
     from models import dsnet_t2 as D
     arrays = {}
@@ -400,7 +498,7 @@ if __name__ == "__main__":
     _install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet", "hanet", "metrics", "keys"]
+    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet", "hanet", "metrics", "keys", "data"]
     if "ops" in which:
         gen_ops()
     if "backbone" in which:
@@ -417,3 +515,5 @@ if __name__ == "__main__":
         gen_metrics()
     if "keys" in which:
         gen_keys()
+    if "data" in which:
+        gen_data()

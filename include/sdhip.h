@@ -318,10 +318,11 @@ int sdhip_dropout_channels(const void* x, int ldx, void* y, int ldy, const long*
  *     4,5   image 0: matching values and size of the branch mask (target[1] == 1 or raw logit[1] == 1)   (Bf1)
  *     6,7   whole batch: #(|pred - gt| * max_disp > 3 and gt > 0), #(gt > 0)                          (err, val_pxl)
  *     8     image 0: #(target[1] == 1)
+ *     9     image 0: pixels scored by the disparity group (denominator of the RMSE / SqRel means)
  *   sums[k], k < SDHIP_METRIC_SUMS (f64): image 0: sum (gt-pred)^2, sum (gt-pred)^2/gt, and the same two over the
  *     pixels with target[1] == 1 (dispRMSE, dispSqRel, branch variants).
  * ------------------------------------------------------------------------- */
-#define SDHIP_METRIC_COUNTS 9
+#define SDHIP_METRIC_COUNTS 10
 #define SDHIP_METRIC_SUMS 4
 #define SDHIP_METRIC_SUM_STRIDE 32   /* doubles per replica of `sums` (one 256-byte line) */
 int sdhip_step_metrics(const void* seg, int lds, const float* seg_target, int ldt, int Ct, const void* disp,

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void step_metrics_kernel(
       const float e = fabsf(dp * max_disp - dg * max_disp) * th;
       c[6] += e > 3.f; c[7] += dg > 0.f;
       if (first) {
+        c[9] += 1;                                    // pixels behind the image-0 means (replayed launches count themselves)
         const float d = dg - dp;
         const float sq = d * d;                       // float32 like the numpy expression
         const float rel = sq / dg;                    // GetSqRel: inf / nan where gt == 0, as in the reference

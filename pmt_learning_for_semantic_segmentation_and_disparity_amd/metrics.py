@@ -20,7 +20,7 @@ from . import _lib
 from ._lib import call, dtype_code, ptr, stream_ptr
 from .ops import _require_gpu, nhwc_view
 
-N_COUNTS, N_SUMS, SUM_STRIDE = 9, 4, 32      # SDHIP_METRIC_COUNTS / _SUMS / _SUM_STRIDE of include/sdhip.h
+N_COUNTS, N_SUMS, SUM_STRIDE = 10, 4, 32      # SDHIP_METRIC_COUNTS / _SUMS / _SUM_STRIDE of include/sdhip.h
 NREP = 32                                    # replicas the workgroups spread their closing atomics over
 
 
@@ -30,7 +30,8 @@ def _safe_div(a, b):
 
 
 class StepMetrics:
-    """Accumulator over the steps of one reporting interval.
+    """Accumulator over the steps of one reporting interval.  All state lives in device memory and `update` is a
+    single kernel launch, so it can sit inside a captured training step (train.TrainStep(metrics=...)).
 
     labels     number of classes L of the segmentation head (`labels = seg.shape[1]`, multiLosses.py:23)
     max_disp   the `max_disp` the reference scales the >3 px test with (multiLosses.py:150)
@@ -44,13 +45,10 @@ class StepMetrics:
         self.rep_stride = ((self.labels ** 2 + N_COUNTS + 31) // 32) * 32       # whole 256-byte lines per replica
         self.counts = torch.zeros(NREP, self.rep_stride, dtype=torch.int64, device=device)
         self.sums = torch.zeros(NREP, SUM_STRIDE, dtype=torch.float64, device=device)
-        self.first_pixels = 0      # pixels of "image 0" seen (for the means of GetDispMetricsNp)
-        self.seg_pixels = 0
 
     def reset(self):
         self.counts.zero_()
         self.sums.zero_()
-        self.first_pixels = self.seg_pixels = 0
 
     def update(self, seg_pred=None, seg_full=None, disp_pred=None, disp=None):
         """seg_pred: raw logits (B,L,H,W) of the head being scored (`init_pred_np`; its argmax equals the argmax of
@@ -88,10 +86,6 @@ class StepMetrics:
              ptr(dv) if dv is not None else None, ptr(gv) if gv is not None else None, ptr(self.counts), ptr(self.sums),
              NREP, self.rep_stride, B, H * W, self.labels, self.max_disp, int(self.mask_invalid), dt, stream_ptr())
         self._keep = (sv, tv, dv, gv)          # alive until the next call (the launch is asynchronous)
-        if disp_pred is not None:
-            self.first_pixels += H * W
-        if seg_pred is not None:
-            self.seg_pixels += H * W
 
     def totals(self):
         """(counts[L*L + N_COUNTS] int64, sums[N_SUMS] f64) on the device, replicas summed."""
@@ -115,7 +109,7 @@ class StepMetrics:
         k = c[L * L:]
         tp, fp, fn = int(k[0]), int(k[1]), int(k[2])
         prec, rec = _safe_div(tp, tp + fp), _safe_div(tp, tp + fn)
-        n1 = self.first_pixels
+        n1 = int(k[9])       # counted on the device, so launches replayed from a hipGraph are included
         rmse = math.sqrt(s[0] / n1) if n1 else float("nan")
         nb = int(k[8])
         return {

@@ -32,8 +32,11 @@ def flatten_parameters(model):
 
 class TrainStep:
     def __init__(self, model, dtype=torch.bfloat16, lr=0.0015, betas=(0.9, 0.999), eps=1e-7, use_lovasz=True,
-                 use_graph=True, world_size=1, process_group=None, use_side_stream=None, loss_fn=None):
+                 use_graph=True, world_size=1, process_group=None, use_side_stream=None, loss_fn=None, metrics=None):
         self.model, self.dtype, self.use_lovasz = model, dtype, use_lovasz
+        # metrics.StepMetrics (or None): scored inside the step on the second segmentation head and the disparity, as the
+        # reference's lossSeg_fn(seg2) / lossDisp_fn calls do (torch_implementation.py:293,304) — one extra launch, graph-safe
+        self.metrics = metrics
         self.loss_fn = loss_fn      # (outputs, seg, disp) -> scalar; default: the joint seg+disp loss of the reference step
         self.lr, self.betas, self.eps = lr, betas, eps
         self.world_size, self.pg = world_size, process_group
@@ -87,6 +90,8 @@ class TrainStep:
             loss = self.loss_fn(outs, seg, disp)
         else:
             loss = ops.train_loss(outs[0], outs[1], outs[2], seg, disp, self.use_lovasz)
+        if self.metrics is not None and self.loss_fn is None:
+            self.metrics.update(outs[2].detach(), seg, outs[1].detach(), disp)
         loss.backward()
         self.ctx.join()             # weight gradients ran on the side stream
         return loss.detach()

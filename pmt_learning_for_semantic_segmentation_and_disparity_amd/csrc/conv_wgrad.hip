@@ -449,6 +449,21 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
     f.in_relu = in_relu; f.bpg = B / groups;
     f.tpb = a.tpb; f.ntg = a.ntg; f.nq = a.nq;
     if (T == 1 && a.tpb == 1) { f.tpb = 1; f.ntg = 1; }
+    f.qb = 0; f.qsh = 0; f.nq_tot = a.nq;
+    // 1x1 with many input channels (DenseNet bottlenecks / transitions): pack 2 or 4 channel chunks per workgroup
+    static const bool no_pack = getenv("SDHIP_WGRAD_NO_PACK") != nullptr;   // diagnostics: A/B against the unpacked kernel
+    // Measured (tools/gpu_wgrad1x1_ab.sh): it pays on large maps and wide outputs (192->128 at 16x64x128: 88 -> 52 us,
+    // 1024->512 at 16x16x32: 62 -> 54 us); on the small maps of the deep DenseNet blocks the sweep is bound by the
+    // per-tile DMA latency either way and the unpacked kernel's smaller tiles win (1024->128 at 16x16x32: 21 vs 31 us).
+    const bool pack_pays = Cout >= 256 || (long)B * H * W >= 100000;
+    if (T == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W && a.nq >= 2 && Cout > 32 && !no_pack &&
+        (pack_pays || getenv("SDHIP_WGRAD_FORCE_PACK"))) {
+      WgfArgs g = f;
+      g.qb = a.nq >= 3 ? 4 : 2; g.qsh = g.qb == 4 ? 2 : 1;
+      g.kh = 1; g.kw = g.qb; g.tpb = g.qb; g.ntg = 1; g.nq = sdhip_cdiv(a.nq, g.qb);
+      const int rc = in_scale ? launch_wgf_packed<false>(g, s) : launch_wgf_packed<true>(g, s);
+      if (rc != 1) return rc;
+    }
     // MB = 32 regroups the taps over two wave groups: the tap grouping must match the instantiation (see launch_wgf_taps)
     const int rc = in_scale ? launch_wgf_taps<false>(f, T, s) : launch_wgf_taps<true>(f, T, s);
     if (rc != 1) return rc;   // 1: no tile fits LDS -> general kernel below

@@ -26,6 +26,15 @@ struct WgfArgs {
   int Cin, ldx, Cout, Mpad, lddy;
   int in_relu, bpg;
   int tpb, ntg, nq;   // taps per workgroup, tap groups, channel chunks
+  // Chunk packing for 1x1 convolutions with many input channels (the DenseNet bottlenecks: dW = dY^T X is a GEMM with few
+  // pixels and 96..1024 input channels): qb = 2 or 4 consecutive 64-channel chunks of a pixel are laid side by side in the
+  // LDS image as if they were qb pixels of a row and walked as the qb "taps" of a 1 x qb kernel with horizontal stride qb.
+  // Row of (pixel p, chunk j) inside a halo line: (p >> 1) * 2qb + 2j + (p & 1) — pixel PAIRS stay on adjacent rows, so the
+  // rows a transposing read touches (p..p+3, p+8..p+11) keep the bank pattern of the unpacked image (rows 4 apart would
+  // all fall into the same 128-byte half of the banks).  One workgroup then multiplies each dY tile with qb chunks instead of one: dY is re-read
+  // nq/qb instead of nq times and the per-tile overhead (barrier, DMA wait) is spread over qb times the MFMAs.
+  // Host sets kh = 1, kw = qb, tpb = qb, ntg = 1, nq = ceil(nq_tot / qb).  qb = 0: off.
+  int qb, qsh, nq_tot;
 };
 
 typedef __attribute__((address_space(3))) bf16x4_t* lds_bf4_p;
@@ -68,7 +77,9 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int s = p.stride, d = p.dil;
-  const int IH = (TH - 1) * s + (p.kh - 1) * d + 1, IW = (TW - 1) * s + (p.kw - 1) * d + 1;
+  const int qb = p.qb, qsh = p.qsh;          // chunk packing (WgfArgs): rows of the X image are (pixel, chunk) pairs
+  const int sw = qb ? qb : s;                // distance of horizontally adjacent output pixels in the X image, in rows
+  const int IH = (TH - 1) * s + (p.kh - 1) * d + 1, IW = (TW - 1) * sw + (p.kw - 1) * d + 1;
   const int IWp = (IW + 15) & ~15;
   const int h_rows = IH * IWp;
   const int h_rounds = (h_rows + RPR - 1) / RPR;
@@ -83,13 +94,14 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   const int q = by % p.nq; by /= p.nq;
   const int kdi = by % p.kd;
   const int mb = by / p.kd;
-  const int t0 = tgi * p.tpb, nt = min(p.tpb, T_ - t0);
+  const int t0 = tgi * p.tpb;
+  const int nt = qb ? min(qb, p.nq_tot - q * qb) : min(p.tpb, T_ - t0);   // packed: "tap" j is channel chunk q*qb + j
   const int m0 = mb * MB;
   const int ci_tile = wave & 3;
   const int rest = wave >> 2;
   const int co_tile0 = (rest % COG) * NCO;
   const int tap_lane = rest / COG;
-  const int cin_q = min(CK, p.Cin - q * CK);
+  const int cin_q = qb ? CK : min(CK, p.Cin - q * CK);   // packed: every flushed chunk writes all 64 columns (pad columns are zeros)
   const int cout_m = min(MB, p.Cout - m0);
 
   f32x4 acc[MAXTW][NCO];
@@ -114,7 +126,16 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   }
   // X halo: row(k-step ks, tap) = ks * KROWS + lane part + tap offset, KROWS a multiple of 16 (swizzle key unchanged)
   const int pa0 = 8 * lg + r4;               // pixel inside the k-step
-  const int lrow = ((pa0 / TW) * s) * IWp + (pa0 % TW) * s;
+  const int ptw = pa0 % TW;
+  const int lrow = ((pa0 / TW) * s) * IWp + (qb ? (ptw >> 1) * 2 * qb + (ptw & 1) : ptw * s);
+  const int tapr = qb ? 2 : 1;               // rows between consecutive "taps" (packed: chunks of one pixel pair interleave)
+  // swizzle key of an X row: that of its PIXEL when chunks are packed (the line pitch is a power of two then)
+  auto xkey = [&](int row) {
+    if (!qb) return WRow::key(row);
+    const int iw = row & (IWp - 1);
+    return WRow::key(((iw >> (qsh + 1)) << 1) | (iw & 1));
+  };
+  auto xoff = [&](int row, int c) { return row * 128 + ((c ^ xkey(row)) << 4); };
   const int krows = (32 / TW) * s * IWp;
   const int cx = ((ci_tile * 16) >> 3) + (p4 >> 1);
   int b_lo[MAXTW], b_hi[MAXTW];
@@ -126,9 +147,9 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
 #pragma unroll
     for (int tl = 0; tl < MAXTW; ++tl) {
       const int tt = tl * TAPL + tap_lane;
-      const int row = tt < nt ? lrow + (khi * d) * IWp + kwi * d : row_first;   // idle slot: result never flushed
-      b_lo[tl] = WRow::off(row, cx) + sub;
-      b_hi[tl] = WRow::off(row + 4 * s, cx) + sub;
+      const int row = tt < nt ? lrow + (khi * d) * IWp + kwi * d * tapr : row_first;   // idle slot: result never flushed
+      b_lo[tl] = xoff(row, cx) + sub;
+      b_hi[tl] = xoff(row + 4 * sw, cx) + sub;
       kwi += TAPL;
       while (kwi >= p.kw) { kwi -= p.kw; ++khi; }
     }
@@ -137,10 +158,13 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   // ---- staging (linear LDS destination, swizzled source: see conv_fast.h) ----
   const int rsub = tid >> 3;
   const int c_l = (tid & 7) ^ WRow::key(rsub);   // logical 16-byte chunk this lane fetches (same in every 64-row round)
+  const int c_lx = (tid & 7) ^ xkey(rsub);      // ... of the X image
   const int tid16 = tid * 16;
   const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);
   const unsigned magic_iwp = div_magic(IWp);
-  const int chx = q * CK + c_l * V;          // first input channel of the lane's chunk
+  // first input channel of the lane's chunk; packed: the chunk index is the row's position inside its pixel, which is the
+  // same in every round (64 and the row pitch are multiples of qb)
+  const int chx = (qb ? q * qb + ((rsub >> 1) & (qb - 1)) : q) * CK + c_lx * V;
   const bool okx = chx < p.Cin;
   const int chy = c_l * V;                   // channel inside the output-channel block
   const bool oky = chy < cout_m;
@@ -168,11 +192,12 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   // (or only feed dW columns nobody reads).
   constexpr int XR = 8;
   int xo[XR], yo[y_rounds];
+  auto xpix = [&](int iw) { return qb ? (((iw >> (qsh + 1)) << 1) | (iw & 1)) : iw; };   // pixel column of a halo-line position
 #pragma unroll
   for (int j = 0; j < XR; ++j) {
     const int row = rsub + j * RPR;
     const int ih = fast_div(row, IWp, magic_iwp), iw = row - ih * IWp;
-    xo[j] = (okx && row < h_rows && iw < IW) ? (ih * p.W + iw) * p.ldx : 0;   // dead pitch columns re-read the tile's first pixel (no traffic)
+    xo[j] = (okx && row < h_rows && iw < IW) ? (ih * p.W + xpix(iw)) * p.ldx : 0;   // dead pitch columns re-read the tile's first pixel (no traffic)
   }
 #pragma unroll
   for (int j = 0; j < y_rounds; ++j) {
@@ -201,7 +226,7 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   auto x_src = [&](const TileGeo& g, int j) -> const T* {
     const int row = rsub + j * RPR;
     const int ih = fast_div(row, IWp, magic_iwp), iw = row - ih * IWp;
-    const int gh = g.ih0 + ih, gw = g.iw0 + iw;
+    const int gh = g.ih0 + ih, gw = g.iw0 + xpix(iw);
     const bool in = okx && g.slice_ok && iw < IW && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
     return in ? g.xb + (gh * p.W + gw) * p.ldx : (const T*)sdhip_zero16;
   };
@@ -218,7 +243,7 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
     const TileGeo g = next_geo();
     const unsigned base = (unsigned)(buf - smem) + wave_lds;
     const bool yin = g.oh0 + TH <= p.Ho && g.ow0 + TW <= p.Wo;                      // wave-uniform
-    const bool xin = g.slice_ok && h_rounds <= XR && g.ih0 >= 0 && g.iw0 >= 0 && g.ih0 + IH <= p.H && g.iw0 + IWp <= p.W;
+    const bool xin = g.slice_ok && h_rounds <= XR && g.ih0 >= 0 && g.iw0 >= 0 && g.ih0 + IH <= p.H && g.iw0 + (qb ? TW : IWp) <= p.W;
     if (yin) {
       const T* yb = oky ? g.yb + (g.oh0 * p.Wo + g.ow0) * p.lddy : (const T*)sdhip_zero16;
 #pragma unroll
@@ -363,12 +388,13 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
 template <int TH, int TW, int MAXT, int MB, bool DMAX>
 int launch_wgf(const WgfArgs& a, hipStream_t s) {
   auto kern = wgrad_fast_kernel<TH, TW, MAXT, MB, DMAX>;
-  const int IH = (TH - 1) * a.stride + (a.kh - 1) * a.dil + 1, IW = (TW - 1) * a.stride + (a.kw - 1) * a.dil + 1;
+  const int IH = (TH - 1) * a.stride + (a.kh - 1) * a.dil + 1, IW = (TW - 1) * (a.qb ? a.qb : a.stride) + (a.kw - 1) * a.dil + 1;
   const int IWp = (IW + 15) & ~15;
   const int hrounds = (IH * IWp + 63) / 64;
   const size_t lds = 2 * ((size_t)hrounds * 8192 + (size_t)TH * TW * 128);
   if (lds > 160 * 1024) return 1;                 // caller tries a smaller tile
   if (!DMAX && hrounds > 5) return 1;             // register-path prefetch plan
+  if (a.qb && (IWp % 64) && (64 % IWp)) return 1;   // packed rows: a lane must meet the same chunk in every load round
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -420,5 +446,9 @@ int launch_wgf_taps(const WgfArgs& a, int T, hipStream_t s) {
   if (a.tpb <= 9) return narrow ? launch_wgf_tile<9, 32, DMAX>(a, s) : launch_wgf_tile<9, 64, DMAX>(a, s);
   return launch_wgf_tile<25, 32, DMAX>(a, s);
 }
+
+// chunk-packed 1x1 weight gradient (WgfArgs::qb): 4x16 pixel tiles, up to 4 chunks as taps
+template <bool DMAX>
+int launch_wgf_packed(const WgfArgs& a, hipStream_t s) { return launch_wgf<4, 16, 4, 64, DMAX>(a, s); }
 
 }  // namespace

@@ -186,3 +186,38 @@ def test_hip_conv_matches_oracle(case, dtype, tol):
     rp = dict(ref.named_parameters())
     for kname, p in mine.named_parameters():
         _close(p.grad, rp[kname].grad, tol, name + "." + kname)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,ldx,Cout,pro,groups", [
+    (4, 16, 32, 1024, 1024, 128, True, 2), (4, 16, 32, 992, 1024, 128, True, 1), (2, 32, 64, 512, 512, 256, True, 1),
+    (2, 32, 48, 192, 256, 128, True, 2), (2, 24, 40, 128, 128, 128, False, 1), (2, 20, 36, 96, 256, 128, True, 1),
+    (2, 16, 16, 160, 160, 64, False, 1), (1, 7, 9, 320, 320, 48, True, 1), (2, 16, 32, 65, 72, 64, False, 1)])
+def test_hip_1x1_wgrad_many_channels(B, H, W, Cin, ldx, Cout, pro, groups):
+    """The chunk-packed 1x1 weight gradient (conv_wgrad_fast.h, WgfArgs::qb): DenseNet bottleneck / transition shapes —
+    input = a channel prefix of a wider slab (ldx > Cin), BatchNorm+ReLU prologue per statistics group, ragged tiles,
+    partial last chunk — against an f32 contraction of the same (bf16-rounded) operands."""
+    import os
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    os.environ["SDHIP_WGRAD_FORCE_PACK"] = "1"      # the launch heuristic would keep these small maps on the unpacked kernel
+    torch.manual_seed(Cin + Cout)
+    dev = torch.device("cuda:0")
+    slab = torch.randn(B, H, W, ldx, device=dev).to(torch.bfloat16)
+    x = slab.permute(0, 3, 1, 2)[:, :Cin]
+    g = (torch.randn(B, H, W, Cout, device=dev) * 0.1).to(torch.bfloat16).permute(0, 3, 1, 2)
+    w = torch.zeros(Cout, Cin, 1, 1, device=dev)
+    sc = (torch.rand(groups, Cin, device=dev) + 0.5) if pro else None
+    sh = (torch.rand(groups, Cin, device=dev) - 0.5) if pro else None
+    spec = ops.ConvSpec('conv', 1, 1, 1, 1, 0, 0, H, W)
+    ops.set_step_context(None)
+    gw, _ = ops._wgrad_impl(x, ldx, g, Cout, w, None, spec, sc, sh, pro, groups)
+    xe = x.float()
+    if pro:
+        per = B // groups
+        s4 = sc.repeat_interleave(per, 0)[:, :, None, None]
+        h4 = sh.repeat_interleave(per, 0)[:, :, None, None]
+        xe = torch.relu(torch.addcmul(h4, xe, s4)).to(torch.bfloat16).float()     # the kernel rounds the prologue result to bf16
+    want = torch.einsum("bmhw,bchw->mc", g.float(), xe)
+    os.environ.pop("SDHIP_WGRAD_FORCE_PACK", None)
+    err = float((gw.reshape(Cout, Cin) - want).norm() / want.norm())
+    assert err < 2e-3, err

@@ -19,6 +19,8 @@ slab:
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -150,21 +152,45 @@ class _DenseBlockFn(torch.autograd.Function):
         return (gx0, None, None) + tuple(flat)
 
 
+def _stem_s2d_weight(w):
+    """The 7x7 / stride 2 / pad 3 stem kernel as the equivalent 4x4 / stride 1 kernel over the 2x2 space-to-depth image:
+    out[o] = sum_k w[k] x[2o + k - 3]; with k + 1 = 2a + r (a < 4, r < 2; the slot k = -1 is a zero) this is
+    sum_a sum_r w'[r][a] X[r][o + a - 2], X[r][j] = x[2j + r] — 16 taps over 4*C channels instead of 49 taps over C = 3
+    channels that fill 3 of the 32 lanes of an MFMA k-step.  Plain (differentiable) tensor ops on a 9 K-element
+    weight: autograd carries the gradient of the 4x4 form back to the (Cout, C, 7, 7) parameter."""
+    Cout, C = w.shape[0], w.shape[1]
+    wp = torch.nn.functional.pad(w, (1, 0, 1, 0))
+    return wp.reshape(Cout, C, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(Cout, 4 * C, 4, 4)
+
+
+def _space_to_depth2(x):
+    """(B, C, H, W) -> (B, 4C, H/2, W/2), channel (ry*2 + rx)*C + c = x[b, c, 2h + ry, 2w + rx]; one strided copy into a
+    channels-last buffer whose pixel stride is padded to 16 bytes."""
+    B, C, H, W = x.shape
+    y, _ = ops.alloc_nhwc(B, 4 * C, H // 2, W // 2, x.dtype, x.device)
+    y.unflatten(1, (2, 2, C)).copy_(x.reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 3, 5, 1, 2, 4))
+    return y
+
+
 class _Stem(torch.autograd.Function):
-    """conv0 (7x7 / 2) -> tap 0 (raw) and relu(norm0(.)): both outputs are used (models/densenet.py:222-225)."""
+    """conv0 (7x7 / 2) -> tap 0 (raw) and relu(norm0(.)): both outputs are used (models/densenet.py:222-225).
+    A (Cout, 4C, 4, 4) weight selects the space-to-depth form (x is then the space-to-depth image)."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, bn, groups):
         B, Cin, H, W = x.shape
         xv, ldx = ops.nhwc_view(x)
-        spec = ops.conv_spec(x, weight, 'conv', 2, 1, 3)
+        if weight.shape[-1] == 4:
+            spec = ops.ConvSpec('conv', 4, 4, 1, 1, 2, 2, H, W)
+        else:
+            spec = ops.conv_spec(x, weight, 'conv', 2, 1, 3)
         Cout = weight.shape[0]
         wp = ops.packed_weight(weight, 'conv', 'fwd', x.dtype)
         c0 = ops.empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
         train = bn.training
         ws = ops._zeros((NREP, groups, 2, Cout), torch.float64, x.device)[0] if train else None
-        ops._conv_launch(xv, ldx, wp, c0, Cout, None, None, None, ws, B, H, W, Cin, spec.Ho, spec.Wo, Cout, 7, 7, 2, 1, 3, 3,
-                         False, groups, 0, False, NREP)
+        ops._conv_launch(xv, ldx, wp, c0, Cout, None, None, None, ws, B, H, W, Cin, spec.Ho, spec.Wo, Cout, spec.kh, spec.kw,
+                         spec.stride, spec.dil, spec.pad_t, spec.pad_l, False, groups, 0, False, NREP)
         count = (B // groups) * spec.Ho * spec.Wo
         scale, shift, mean, invstd = ops._bn_finalize(ws, NREP, bn, count, groups)
         f = ops.empty_nhwc(B, Cout, spec.Ho, spec.Wo, x.dtype, x.device)
@@ -264,7 +290,17 @@ class DenseNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward(self, x, groups=1):
-        c0, f = _Stem.apply(x, self.conv0.weight, self.features.norm0.weight, self.features.norm0.bias, self.features.norm0, groups)
+        w0 = self.conv0.weight
+        # The space-to-depth form sums the 147 products of an output in another order than the 7x7 form.  Exact in exact
+        # arithmetic and at the f32 rounding level per output (2e-7), but train-mode BatchNorm over tiny batches amplifies
+        # any such reordering (tools/gpu_stem_diag.py), so the f32 parity path keeps the 7x7 form that the golden vectors
+        # were captured with; the bf16 throughput path takes the 2 % faster step.  SDHIP_STEM_S2D=0/1 forces either.
+        s2d = os.environ.get("SDHIP_STEM_S2D")
+        use_s2d = (x.dtype == torch.bfloat16) if s2d is None else s2d == "1"
+        if use_s2d and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            # (the image may arrive zero-padded to 8 channels for the 7x7 kernels: only the weight's channels are real)
+            x, w0 = _space_to_depth2(x[:, :w0.shape[1]]), _stem_s2d_weight(w0)
+        c0, f = _Stem.apply(x, w0, self.features.norm0.weight, self.features.norm0.bias, self.features.norm0, groups)
         taps = [c0]
         f = ops.maxpool3s2(f)
         stats = None

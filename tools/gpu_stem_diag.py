@@ -1,0 +1,47 @@
+"""Per-parameter gradient error of the DenseNet towers against the CPU oracle, for the 7x7 stem and its space-to-depth
+form (SDHIP_STEM_S2D=1 / 0): shows that the deep, cancellation-dominated BatchNorm bias gradients move by the same amount
+under any change of the f32 summation order in the stem."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import ref_models as R
+from oracle.detweights import fill_state_dict, rand_input
+from pmt_learning_for_semantic_segmentation_and_disparity_amd.densenet import densenet121
+
+ref = fill_state_dict(R.densenet121(), 21).train()
+x = rand_input(21, "img", (2, 3, 256, 256))
+wts = [rand_input(22, "g%d" % i, (1,)).item() + 0.5 for i in range(5)]
+sum(w * (t * t).mean() for w, t in zip(wts, ref(x))).backward()
+rp = dict(ref.named_parameters())
+# the same gradients in float64: how far the reference's own f32 arithmetic is from the exact value
+import copy
+ref64 = copy.deepcopy(ref).double()
+ref64.zero_grad()
+sum(w * (t * t).mean() for w, t in zip(wts, ref64(x.double()))).backward()
+r64 = {k: p.grad for k, p in ref64.named_parameters() if p.grad is not None}
+res = {}
+for mode in ("s2d", "7x7"):
+    os.environ["SDHIP_STEM_S2D"] = "1" if mode == "s2d" else "0"
+    mine = densenet121()
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.cuda().train()
+    outs = mine(x.cuda())
+    with torch.no_grad():
+        rt = ref(x)
+        print(mode, "forward tap rel errors", ["%.2e" % float((a.float().cpu() - b).norm() / b.norm()) for a, b in zip(outs, rt)])
+    sum(w * (t.float() * t.float()).mean() for w, t in zip(wts, outs)).backward()
+    errs = {}
+    for k, p in mine.named_parameters():
+        if rp[k].grad is None:
+            continue
+        want = rp[k].grad
+        errs[k] = float(torch.linalg.norm(p.grad.cpu().double() - r64[k]) / torch.linalg.norm(r64[k]).clamp_min(1e-12))
+    res[mode] = errs
+res["ref32"] = {k: float(torch.linalg.norm(rp[k].grad.double() - r64[k]) / torch.linalg.norm(r64[k]).clamp_min(1e-12)) for k in res["s2d"]}
+top = sorted(res["s2d"], key=lambda k: -max(res["s2d"][k], res["7x7"][k]))[:10]
+for k in top:
+    print("%-50s s2d %.4f   7x7 %.4f   cpu-f32 %.4f   |grad| %.3e" % (k, res["s2d"][k], res["7x7"][k], res["ref32"][k], float(rp[k].grad.norm())))
+for k in ("conv0.weight", "features.norm0.weight", "features.norm0.bias"):
+    print("%-50s s2d %.5f   7x7 %.5f" % (k, res["s2d"][k], res["7x7"][k]))
+import statistics
+print("median s2d %.5f 7x7 %.5f cpu-f32 %.5f ; max s2d %.4f 7x7 %.4f cpu-f32 %.4f" % (statistics.median(res["s2d"].values()), statistics.median(res["7x7"].values()), statistics.median(res["ref32"].values()), max(res["s2d"].values()), max(res["7x7"].values()), max(res["ref32"].values())))

@@ -123,7 +123,10 @@ class SamplePreparer:
         return mk(3, self.dtype), mk(3, self.dtype), mk(self.n_seg, torch.float32), mk(1, torch.float32)
 
     def _dev(self, a):
-        t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device, non_blocking=True)
+        a = np.ascontiguousarray(a)
+        if not a.flags.writeable:          # PIL hands out read-only views; torch wants to own a writable buffer
+            a = a.copy()
+        t = torch.from_numpy(a).to(self.device, non_blocking=True)
         self._keep.append(t)
         return t
 

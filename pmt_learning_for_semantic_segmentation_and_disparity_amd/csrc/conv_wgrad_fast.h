@@ -2,9 +2,9 @@
 // kernel: dW[t][m][k] = sum over pixels of dY[pix][m] * Xeff[pix shifted by tap t][k]).
 //
 // What differs from the general kernel:
-//  * X halo tile and dY tile are DOUBLE-BUFFERED in LDS and filled by LDS-DMA (global_load_lds; the X tile goes through
-//    registers, prefetched behind the MFMAs, when a BatchNorm prologue or an odd channel tail has to be applied on the
-//    way): the loads of tile i+1 fly while tile i is multiplied, one barrier per tile.
+//  * X halo tile and dY tile are DOUBLE-BUFFERED in LDS and filled by LDS-DMA (global_load_lds): the loads of tile i+1
+//    fly while tile i is multiplied, one barrier per tile.  When a BatchNorm prologue has to be applied on the way, both
+//    operands go through registers instead, prefetched TWO tiles ahead in two register sets (see the sweep).
 //  * LDS images use the linear-destination / swizzled-source layout of conv_fast.h (chunk slot = c ^ (row & 6), row
 //    pitch of the halo tile a multiple of 8), so the byte address of a transposing fragment read is
 //        per-lane base (one per tap, computed ONCE per kernel)  +  k-step offset (wave-uniform)
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   constexpr int MAXTW = (MAXT + TAPL - 1) / TAPL;
   constexpr int NKS = TH * TW / 32;          // MFMA k-steps (32 pixels) per tile
   constexpr int RPR = 64;                    // LDS rows per load round of the 512 lanes
-  constexpr int XPF = 5;                     // register-path X loads per lane (rounds) kept in flight
+  constexpr int XPF = MAXT == 1 ? (TH * TW) / 64 : 5;   // register-path X loads per lane (rounds) per tile; a stride-1 1x1 halo IS the tile
   static_assert(TH * TW % 64 == 0 && (TW == 32 || TW == 16), "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -173,8 +173,6 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   const int ntiles = p.B * p.Do * tiles_h * tiles_w;
 
   float psc[V], psf[V];                      // prologue coefficients of the lane's 8 channels (per tile: the group may change)
-  u32x4 rx[XPF];
-  bool rin[XPF];
 
   // Tile walk without divisions: (image, tile row, tile column) of the NEXT tile to issue advance by gridDim.x tiles.
   int n_img, n_ty, n_tx;
@@ -237,9 +235,7 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
     const bool in = oky && oh < p.Ho && ow < p.Wo;
     return in ? g.yb + (oh * p.Wo + ow) * p.lddy : (const T*)sdhip_zero16;
   };
-  int pend_grp = 0;       // statistics group of the tile whose X loads are pending in rx[] (register path)
-  bool pend_all = false;  // ... and whether it was an interior tile (every lane loaded)
-  auto issue = [&](unsigned char* buf) {
+  auto issue = [&](unsigned char* buf) {     // LDS-DMA of the next tile (no prologue: DMAX)
     const TileGeo g = next_geo();
     const unsigned base = (unsigned)(buf - smem) + wave_lds;
     const bool yin = g.oh0 + TH <= p.Ho && g.ow0 + TW <= p.Wo;                      // wave-uniform
@@ -253,77 +249,19 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
       for (int j = 0; j < y_rounds; ++j) glds16(y_src(g, j), base + xbytes + j * 8192);
     }
     const T* xbi = okx ? g.xb + (g.ih0 * p.W + g.iw0) * p.ldx : (const T*)sdhip_zero16;
-    if constexpr (DMAX) {
-      if (xin) {
+    if (xin) {
 #pragma unroll
-        for (int j = 0; j < XR; ++j)
-          if (j < h_rounds) glds16(xbi + xo[j], base + j * 8192);
-      } else {
-        for (int j = 0; j < h_rounds; ++j) glds16(x_src(g, j), base + j * 8192);
-      }
+      for (int j = 0; j < XR; ++j)
+        if (j < h_rounds) glds16(xbi + xo[j], base + j * 8192);
     } else {
-      pend_grp = g.grp; pend_all = xin;
-      if (xin) {
-#pragma unroll
-        for (int j = 0; j < XPF; ++j)
-          if (j < h_rounds) rx[j] = *reinterpret_cast<const u32x4*>(xbi + xo[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < XPF; ++j) {
-          if (j < h_rounds) {
-            const T* src = x_src(g, j);
-            rin[j] = src != (const T*)sdhip_zero16;
-            rx[j] = *reinterpret_cast<const u32x4*>(src);
-          }
-        }
-      }
+      for (int j = 0; j < h_rounds; ++j) glds16(x_src(g, j), base + j * 8192);
     }
   };
+  (void)issue;
   int cur_grp = -1;
-  auto commit = [&](unsigned char* buf) {   // register path: BatchNorm prologue, then LDS
-    if constexpr (!DMAX) {
-      if (p.in_scale && pend_grp != cur_grp) {   // wave-uniform; the group changes at most once per sweep
-        cur_grp = pend_grp;
-        const float* sc = p.in_scale + cur_grp * p.Cin + chx;
-        const float* sf = p.in_shift + cur_grp * p.Cin + chx;
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const bool okc = chx + e < p.Cin;
-          psc[e] = okc ? sc[okc ? e : 0] : 0.f;
-          psf[e] = okc ? sf[okc ? e : 0] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < XPF; ++j) {
-        if (j < h_rounds) {
-          const bool in = pend_all || rin[j];
-          u32x4 raw = in ? rx[j] : u32x4{0u, 0u, 0u, 0u};
-          if (in && p.in_scale) {
-            float f[V];
-            Chunk<T>::unpack(raw, f);
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-              const float v = fmaf(f[e], psc[e], psf[e]);   // pad channels (>= Cin) only feed dW columns nobody reads
-              f[e] = p.in_relu ? fmaxf(v, 0.f) : v;
-            }
-            raw = Chunk<T>::pack(f);
-          }
-          *reinterpret_cast<u32x4*>(buf + j * 8192 + tid16) = raw;
-        }
-      }
-    }
-  };
 
-  // ---- sweep ----
-  const int ntl = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // this workgroup's tiles
-  if (ntl > 0) issue(smem);
-  for (int it = 0; it < ntl; ++it) {
-    unsigned char* buf = smem + (it & 1) * sbytes;
-    commit(buf);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's DMA has landed
-    __syncthreads();                                    // tile visible; everybody has finished tile it-1 (other buffer)
-    if (it + 1 < ntl) issue(smem + ((it + 1) & 1) * sbytes);
-
+  // ---- one tile's arithmetic on a filled stage buffer ----
+  auto compute = [&](unsigned char* buf) {
     if (p.dbias && q == 0 && tgi == 0 && kdi == p.pad_d) {  // uniform: bias gradient = column sums of the dY tile (once)
       const int ch = tid % CK, stripe = tid / CK;
       if (ch < cout_m) {
@@ -359,6 +297,114 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
       if (u + PD < NST) bfr[u % PD] = ldb(u + PD);
       __builtin_amdgcn_sched_barrier(0);   // keep the lookahead: the scheduler otherwise sinks each read next to its use
     }
+  };
+
+  // ---- sweep ----
+  const int ntl = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // this workgroup's tiles
+  if constexpr (DMAX) {
+    if (ntl > 0) issue(smem);
+    for (int it = 0; it < ntl; ++it) {
+      unsigned char* buf = smem + (it & 1) * sbytes;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's DMA has landed
+      __syncthreads();                                    // tile visible; everybody has finished tile it-1 (other buffer)
+      if (it + 1 < ntl) issue(smem + ((it + 1) & 1) * sbytes);
+      compute(buf);
+    }
+  } else {
+    // Register path (BatchNorm prologue on X): BOTH operands of a tile travel through registers, two tiles ahead.  With
+    // the loads of tile it+1 issued after the barrier of tile it (the DMA scheme above) a workgroup of the small-map
+    // layers spends most of each tile waiting for HBM: its MFMA phase (8..72 MFMAs per wave) is far shorter than a load.
+    // Two register sets double the time a load has to land, and since every load is a plain register load the compiler
+    // places exact vmcnt waits (LDS-DMA is invisible to it and would force vmcnt(0)).
+    struct RegSet { u32x4 x[XPF]; u32x4 y[y_rounds]; bool rin[XPF]; int grp; bool all; };
+    RegSet ra, rb;
+    auto load = [&](RegSet& r) {
+      const TileGeo g = next_geo();
+      const bool yin = g.oh0 + TH <= p.Ho && g.ow0 + TW <= p.Wo;                      // wave-uniform
+      const bool xin = g.slice_ok && h_rounds <= XR && g.ih0 >= 0 && g.iw0 >= 0 && g.ih0 + IH <= p.H && g.iw0 + (qb ? TW : IWp) <= p.W;
+      r.grp = g.grp; r.all = xin;
+      const T* xbi = okx ? g.xb + (g.ih0 * p.W + g.iw0) * p.ldx : (const T*)sdhip_zero16;
+      if (xin) {
+#pragma unroll
+        for (int j = 0; j < XPF; ++j)
+          if (j < h_rounds) r.x[j] = *reinterpret_cast<const u32x4*>(xbi + xo[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < XPF; ++j) {
+          if (j < h_rounds) {
+            const T* src = x_src(g, j);
+            r.rin[j] = src != (const T*)sdhip_zero16;
+            r.x[j] = *reinterpret_cast<const u32x4*>(src);
+          }
+        }
+      }
+      if (yin) {
+        const T* yb = oky ? g.yb + (g.oh0 * p.Wo + g.ow0) * p.lddy : (const T*)sdhip_zero16;
+#pragma unroll
+        for (int j = 0; j < y_rounds; ++j) r.y[j] = *reinterpret_cast<const u32x4*>(yb + yo[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < y_rounds; ++j) r.y[j] = *reinterpret_cast<const u32x4*>(y_src(g, j));
+      }
+    };
+    auto store = [&](RegSet& r, unsigned char* buf) {   // BatchNorm prologue on X, then both operands into LDS
+      if (p.in_scale && r.grp != cur_grp) {   // wave-uniform; the group changes at most once per sweep
+        cur_grp = r.grp;
+        const float* sc = p.in_scale + cur_grp * p.Cin + chx;
+        const float* sf = p.in_shift + cur_grp * p.Cin + chx;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const bool okc = chx + e < p.Cin;
+          psc[e] = okc ? sc[okc ? e : 0] : 0.f;
+          psf[e] = okc ? sf[okc ? e : 0] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < XPF; ++j) {
+        if (j < h_rounds) {
+          const bool in = r.all || r.rin[j];
+          u32x4 raw = in ? r.x[j] : u32x4{0u, 0u, 0u, 0u};
+          if (in && p.in_scale) {
+            float f[V];
+            Chunk<T>::unpack(raw, f);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+              const float v = fmaf(f[e], psc[e], psf[e]);   // pad channels (>= Cin) only feed dW columns nobody reads
+              f[e] = p.in_relu ? fmaxf(v, 0.f) : v;
+            }
+            raw = Chunk<T>::pack(f);
+          }
+          *reinterpret_cast<u32x4*>(buf + j * 8192 + tid16) = raw;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < y_rounds; ++j) *reinterpret_cast<u32x4*>(buf + xbytes + j * 8192 + tid16) = r.y[j];
+    };
+    if constexpr (MAXT <= 9) {
+      if (ntl > 0) load(ra);
+      if (ntl > 1) load(rb);
+      for (int it = 0; it < ntl; it += 2) {
+        store(ra, smem);
+        __syncthreads();                    // tile visible; everybody has finished tile it-2 in this buffer (see tile it-1's barrier)
+        if (it + 2 < ntl) load(ra);
+        compute(smem);
+        if (it + 1 < ntl) {                 // uniform
+          store(rb, smem + sbytes);
+          __syncthreads();
+          if (it + 3 < ntl) load(rb);
+          compute(smem + sbytes);
+        }
+      }
+    } else {                                // 25 taps: the accumulators leave no room for a second register set
+      if (ntl > 0) load(ra);
+      for (int it = 0; it < ntl; ++it) {
+        unsigned char* buf = smem + (it & 1) * sbytes;
+        store(ra, buf);
+        __syncthreads();
+        if (it + 1 < ntl) load(ra);
+        compute(buf);
+      }
+    }
   }
 
   // ---- flush: f32 atomics into the packed gradient buffer [kd][nq][T][Mpad][CK] ----
@@ -393,7 +439,7 @@ int launch_wgf(const WgfArgs& a, hipStream_t s) {
   const int hrounds = (IH * IWp + 63) / 64;
   const size_t lds = 2 * ((size_t)hrounds * 8192 + (size_t)TH * TW * 128);
   if (lds > 160 * 1024) return 1;                 // caller tries a smaller tile
-  if (!DMAX && hrounds > 5) return 1;             // register-path prefetch plan
+  if (!DMAX && hrounds > (MAXT == 1 ? (TH * TW) / 64 : 5)) return 1;             // register-path prefetch plan (XPF in the kernel)
   if (a.qb && (IWp % 64) && (64 % IWp)) return 1;   // packed rows: a lane must meet the same chunk in every load round
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {

@@ -191,6 +191,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(2, a.height, a.width, a.cpu_steps, a.cpu_threads)
         print(json.dumps(out))
     if world > 1:
+        torch.distributed.barrier()     # rank 0 may still be in its single-rank roofline measurement: leave together
         torch.distributed.destroy_process_group()
 
 

@@ -427,6 +427,21 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
     t.B = B; t.H = H; t.W = W; t.Ho = Ho; t.Wo = Wo; t.kh = kh; t.kw = kw; t.dil = dil; t.pad_t = pad_t; t.pad_l = pad_l;
     t.Cin = Cin; t.ldx = ldx; t.lddy = lddy; t.Mpad = a.Mpad;
     const long npix = (long)B * Ho * Wo;
+    // large maps, bf16: the LDS-tiled kernel (lanes = (tap, channel pair), 8 x 64 pixel tiles)
+    {
+      const int IHt = 8 + (kh - 1) * dil, IWt = 64 + (kw - 1) * dil, P = IWt + 2;
+      const size_t lds = (size_t)IHt * P * 16 + 8 * 64 * 2;
+      static const bool no_tiled = getenv("SDHIP_THIN_WGRAD_REG") != nullptr;   // diagnostics: A/B against the register kernel
+      if (dtype == SDHIP_BF16 && T > 9 && 8 * T <= 256 && lds <= 60 * 1024 && Wo >= 64 && Ho >= 8 && npix >= 65536 && !no_tiled) {
+        const int th = sdhip_cdiv(Ho, 8), tw = sdhip_cdiv(Wo, 64);
+        const int ntiles = B * th * tw;
+        // one flush of T x 8 atomics per workgroup lands on T cache lines, ~50 ns per request and line: 256 workgroups
+        const int blocks = ntiles < 256 ? ntiles : 256;
+        hipLaunchKernelGGL((conv_thin_wgrad_tiled_kernel<25>), dim3(blocks), dim3(256), lds, s, t, th, tw, IHt, IWt, P);
+        SDHIP_LAUNCH_CHECK();
+        return SDHIP_OK;
+      }
+    }
     const int blocks = (int)(npix / 256 < 1024 ? (npix + 255) / 256 : 1024);   // measured: 128 / 1024 workgroups -> 150 / 95 us
     if (dtype == SDHIP_BF16) {
       if (T <= 9) hipLaunchKernelGGL((conv_thin_wgrad_kernel<bf16_t, 9>), dim3(blocks), dim3(256), 0, s, t);

@@ -221,3 +221,30 @@ def test_hip_1x1_wgrad_many_channels(B, H, W, Cin, ldx, Cout, pro, groups):
     os.environ.pop("SDHIP_WGRAD_FORCE_PACK", None)
     err = float((gw.reshape(Cout, Cin) - want).norm() / want.norm())
     assert err < 2e-3, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,bias", [(2, 128, 256, 8, True), (2, 130, 250, 8, False), (1, 256, 512, 3, True)])
+def test_hip_thin_wgrad_tiled(B, H, W, Cin, bias):
+    """5x5 dilation-2 'same' convolution of an <= 8-channel image to ONE channel (conv2d_ba* of models/dsnet_t2.py): the
+    LDS-tiled weight-gradient kernel (conv_thin.h) on full-size and ragged maps against autograd on the same bf16-rounded
+    operands."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    torch.manual_seed(B * H + Cin)
+    dev = torch.device("cuda:0")
+    x8 = torch.zeros(B, H, W, 8, device=dev, dtype=torch.bfloat16)
+    x8[..., :Cin] = torch.randn(B, H, W, Cin, device=dev).to(torch.bfloat16)
+    x = x8.permute(0, 3, 1, 2)[:, :Cin]
+    g1 = (torch.randn(B, H, W, 1, device=dev) * 0.1).to(torch.bfloat16).permute(0, 3, 1, 2)
+    w = torch.zeros(1, Cin, 5, 5, device=dev)
+    b = torch.zeros(1, device=dev) if bias else None
+    spec = ops.ConvSpec('conv', 5, 5, 1, 2, 4, 4, H, W)
+    ops.set_step_context(None)
+    gw, gb = ops._wgrad_impl(x, 8, g1, 1, w, b, spec, None, None, False, 1)
+    wr = torch.zeros(1, Cin, 5, 5, device=dev, requires_grad=True)
+    y = torch.nn.functional.conv2d(x.float(), wr, None, 1, 4, 2)
+    (y * g1.float()).sum().backward()
+    err = float((gw - wr.grad).norm() / wr.grad.norm())
+    assert err < 1e-4, err
+    if bias:
+        assert abs(float(gb) - float(g1.float().sum())) <= 1e-3 * max(1.0, abs(float(g1.float().sum())))

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_thin_wgrad_kernel(const ThinWgArgs p
 
 // LDS-tiled bf16 variant of the above for full-resolution maps.  The register version keeps T x 8 sums per lane (200
 // VGPRs for 5x5: two waves per SIMD) and walks its pixels one by one, every tap a separate L1 round trip: 129 us on
-// 8 x 256 x 512 where the data is 19 MB.  Here a workgroup stages an 8 x 64 pixel tile of dY and its X halo in LDS and the
+// 8 x 256 x 512 where the data is 19 MB (this kernel: 33 us).  Here a workgroup stages an 8 x 64 pixel tile of dY and its X halo in LDS and the
 // LANES take the (tap, channel pair) outputs: lane = (half of the tile rows, tap, channel pair) runs along its rows with
 // one 4-byte LDS read and two FMAs per pixel (the dY values arrive 8 at a time as one broadcast read).
 template <int MAXT>

@@ -435,8 +435,10 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
       if (dtype == SDHIP_BF16 && T > 9 && 8 * T <= 256 && lds <= 60 * 1024 && Wo >= 64 && Ho >= 8 && npix >= 65536 && !no_tiled) {
         const int th = sdhip_cdiv(Ho, 8), tw = sdhip_cdiv(Wo, 64);
         const int ntiles = B * th * tw;
-        // one flush of T x 8 atomics per workgroup lands on T cache lines, ~50 ns per request and line: 256 workgroups
-        const int blocks = ntiles < 256 ? ntiles : 256;
+        // measured at 8 x 256 x 512 (tools/gpu_thinwg.py): 128 / 256 / 512 / 1024 / 2048 workgroups -> 96 / 51 / 33 / 33 / 38 us:
+        // the single-buffered tiles want several workgroups per CU; past 1024 the T x 8 flush atomics per workgroup show
+        static const int cap = getenv("SDHIP_TUNE_THIN_BLOCKS") ? atoi(getenv("SDHIP_TUNE_THIN_BLOCKS")) : 1024;
+        const int blocks = ntiles < cap ? ntiles : cap;
         hipLaunchKernelGGL((conv_thin_wgrad_tiled_kernel<25>), dim3(blocks), dim3(256), lds, s, t, th, tw, IHt, IWt, P);
         SDHIP_LAUNCH_CHECK();
         return SDHIP_OK;

@@ -197,15 +197,20 @@ __global__ __launch_bounds__(256) void resize_fwd(const T* __restrict__ x, Img i
 //   gx[o, i, r, c] = sum over d with weight(d -> i) * gy[o, d, r, c]
 // layout: [outer][axis][inner pixels][C]; a source index i receives from destinations whose
 // (nearest or linear) source set contains i; candidates are bounded by the scale.
+// `split` (1, 4 or 16, a power of two) lanes share one output item and take every split-th candidate: the pooled
+// pyramid branches are upsampled 16-64x, so an item has up to ~130 candidates while there are only a few thousand items —
+// one lane per item walked them in a serial, latency-bound chain (28 us per pass on tensors of a few MB).
 template <typename T, bool VEC, typename TO>
 __global__ __launch_bounds__(256) void resize_bwd_axis(const T* __restrict__ gy, int ldg, TO* __restrict__ gx, int ldx,
-                                                       long outer, int inner, int C, Axis a) {
+                                                       long outer, int inner, int C, Axis a, int split) {
   constexpr int N = Unit<T, VEC>::N;
   const int units = C / N;
   const long npix = outer * a.in * inner;
-  for (long it = (long)blockIdx.x * 256 + threadIdx.x;; it += (long)gridDim.x * 256) {
+  const int sub = threadIdx.x & (split - 1);
+  const int per_block = 256 / split;
+  for (long it = (long)blockIdx.x * per_block + threadIdx.x / split;; it += (long)gridDim.x * per_block) {
     long pix; int c0;
-    if (!item<N>(it, npix, units, pix, c0)) break;
+    if (!item<N>(it, npix, units, pix, c0)) break;       // uniform over the lanes of an item
     const int r = (int)(pix % inner);
     const int i = (int)((pix / inner) % a.in);
     const long o = pix / ((long)inner * a.in);
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256) void resize_bwd_axis(const T* __restrict__ gy,
     if (a.scale <= 0.f) { lo = 0; hi = a.out - 1; }
     if (lo < 0) lo = 0;
     if (hi > a.out - 1) hi = a.out - 1;
-    for (int d = lo; d <= hi; ++d) {
+    for (int d = lo + sub; d <= hi; d += split) {
       float wgt = 0.f;
       if (a.mode == 0) {
         wgt = nearest_src(a, d) == i ? 1.f : 0.f;
@@ -235,6 +240,10 @@ __global__ __launch_bounds__(256) void resize_bwd_axis(const T* __restrict__ gy,
         for (int e = 0; e < N; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
       }
     }
+    for (int o2 = split >> 1; o2 > 0; o2 >>= 1)
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] += __shfl_xor(acc[e], o2, 64);
+    if (sub != 0) continue;
     TO* dst = gx + pix * ldx + c0;
     if constexpr (sizeof(TO) == sizeof(T)) {
       Unit<T, VEC>::store(reinterpret_cast<T*>(dst), acc);
@@ -425,18 +434,23 @@ extern "C" int sdhip_resize_bwd(const void* gy, int ldg, void* gx, int ldgx, flo
   const long np1 = (long)B * Ho * W;
   // pass 2: along H.  layout [outer = B][axis = H][inner = W][C]; input tmp (f32), output gx (T)
   const long np2 = (long)B * H * W;
+  auto lanes = [](const Axis& a) {      // candidates per item ~ 2 / scale + 5 (see the kernel's [lo, hi] window)
+    const float span = a.scale > 0.f ? 2.f / a.scale + 5.f : (float)a.out;
+    return span >= 32.f ? 16 : span >= 12.f ? 4 : 1;
+  };
+  const int sw = lanes(aw), sh = lanes(ah);
   if (dtype == SDHIP_F32) {
     const bool v1 = vec_ok<float>(C, {ldg}, {gy, tmp}), v2 = vec_ok<float>(C, {ldgx}, {gx, tmp});
-    if (v1) hipLaunchKernelGGL((resize_bwd_axis<float, true, float>), grid_for(np1 * (C / 4)), dim3(256), 0, s, (const float*)gy, ldg, tmp, C, (long)B * Ho, 1, C, aw);
-    else hipLaunchKernelGGL((resize_bwd_axis<float, false, float>), grid_for(np1 * C), dim3(256), 0, s, (const float*)gy, ldg, tmp, C, (long)B * Ho, 1, C, aw);
-    if (v2) hipLaunchKernelGGL((resize_bwd_axis<float, true, float>), grid_for(np2 * (C / 4)), dim3(256), 0, s, (const float*)tmp, C, (float*)gx, ldgx, (long)B, W, C, ah);
-    else hipLaunchKernelGGL((resize_bwd_axis<float, false, float>), grid_for(np2 * C), dim3(256), 0, s, (const float*)tmp, C, (float*)gx, ldgx, (long)B, W, C, ah);
+    if (v1) hipLaunchKernelGGL((resize_bwd_axis<float, true, float>), grid_for(np1 * (C / 4) * sw), dim3(256), 0, s, (const float*)gy, ldg, tmp, C, (long)B * Ho, 1, C, aw, sw);
+    else hipLaunchKernelGGL((resize_bwd_axis<float, false, float>), grid_for(np1 * C * sw), dim3(256), 0, s, (const float*)gy, ldg, tmp, C, (long)B * Ho, 1, C, aw, sw);
+    if (v2) hipLaunchKernelGGL((resize_bwd_axis<float, true, float>), grid_for(np2 * (C / 4) * sh), dim3(256), 0, s, (const float*)tmp, C, (float*)gx, ldgx, (long)B, W, C, ah, sh);
+    else hipLaunchKernelGGL((resize_bwd_axis<float, false, float>), grid_for(np2 * C * sh), dim3(256), 0, s, (const float*)tmp, C, (float*)gx, ldgx, (long)B, W, C, ah, sh);
   } else {
     const bool v1 = vec_ok<bf16_t>(C, {ldg}, {gy});
-    if (v1) hipLaunchKernelGGL((resize_bwd_axis<bf16_t, true, float>), grid_for(np1 * (C / 8)), dim3(256), 0, s, (const bf16_t*)gy, ldg, tmp, C, (long)B * Ho, 1, C, aw);
-    else hipLaunchKernelGGL((resize_bwd_axis<bf16_t, false, float>), grid_for(np1 * C), dim3(256), 0, s, (const bf16_t*)gy, ldg, tmp, C, (long)B * Ho, 1, C, aw);
+    if (v1) hipLaunchKernelGGL((resize_bwd_axis<bf16_t, true, float>), grid_for(np1 * (C / 8) * sw), dim3(256), 0, s, (const bf16_t*)gy, ldg, tmp, C, (long)B * Ho, 1, C, aw, sw);
+    else hipLaunchKernelGGL((resize_bwd_axis<bf16_t, false, float>), grid_for(np1 * C * sw), dim3(256), 0, s, (const bf16_t*)gy, ldg, tmp, C, (long)B * Ho, 1, C, aw, sw);
     // second pass reads f32, writes bf16: scalar units keep it simple (the tensor is the small, pre-upsampling one)
-    hipLaunchKernelGGL((resize_bwd_axis<float, false, bf16_t>), grid_for(np2 * C), dim3(256), 0, s, (const float*)tmp, C, (bf16_t*)gx, ldgx, (long)B, W, C, ah);
+    hipLaunchKernelGGL((resize_bwd_axis<float, false, bf16_t>), grid_for(np2 * C * sh), dim3(256), 0, s, (const float*)tmp, C, (bf16_t*)gx, ldgx, (long)B, W, C, ah, sh);
   }
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;

@@ -154,7 +154,16 @@ Layout layout(long npix, int C) {
   return L;
 }
 
+// every kernel here ends with a few atomics per workgroup on the same counters (class counts, per-class f64 sums): 2048
+// workgroups queued ~30 us of same-address atomics behind 10 us of streaming, so the grid is kept at two per CU
 inline dim3 grid_for(long items) {
+  long b = (items + 255) / 256;
+  if (b > 512) b = 512;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+inline dim3 grid_stream(long items) {   // no closing atomics: fill the chip
   long b = (items + 255) / 256;
   if (b > 2048) b = 2048;
   if (b < 1) b = 1;
@@ -203,9 +212,9 @@ extern "C" int sdhip_lovasz_softmax(const void* logits, int ldy, const float* ta
   dim3 g2 = grid_for(npix); g2.y = C;
   hipLaunchKernelGGL(lovasz_grad_kernel, g2, dim3(256), 0, s, keys_out, vals_out, cum, counts, gerr, lossc, npix);
   if (dtype == SDHIP_F32)
-    hipLaunchKernelGGL(lovasz_backward_kernel<float>, grid_for(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, gerr, counts, lossc, (float*)grad, ldg, loss, npix, C, weight);
+    hipLaunchKernelGGL(lovasz_backward_kernel<float>, grid_stream(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, gerr, counts, lossc, (float*)grad, ldg, loss, npix, C, weight);
   else
-    hipLaunchKernelGGL(lovasz_backward_kernel<bf16_t>, grid_for(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, gerr, counts, lossc, (bf16_t*)grad, ldg, loss, npix, C, weight);
+    hipLaunchKernelGGL(lovasz_backward_kernel<bf16_t>, grid_stream(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, gerr, counts, lossc, (bf16_t*)grad, ldg, loss, npix, C, weight);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }

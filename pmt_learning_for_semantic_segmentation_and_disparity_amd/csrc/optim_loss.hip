@@ -100,6 +100,14 @@ inline dim3 grid_for(long items) {
   return dim3((unsigned)b);
 }
 
+// the loss kernels end with ONE f64 atomic per workgroup on the same scalar: two workgroups per CU instead of eight
+inline dim3 grid_loss(long items) {
+  long b = (items + 255) / 256;
+  if (b > 512) b = 512;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
 }  // namespace
 
 extern "C" int sdhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* beta_pow,
@@ -122,9 +130,9 @@ extern "C" int sdhip_ce_loss(const void* logits, int ldy, const float* target, i
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "ce_loss: unknown dtype %d", dtype);
   const float wn = weight / (float)npix;
   if (dtype == SDHIP_F32)
-    hipLaunchKernelGGL(ce_kernel<float>, grid_for(npix), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ldy, target, ldt, (float*)grad, ldg, loss, npix, C, wn);
+    hipLaunchKernelGGL(ce_kernel<float>, grid_loss(npix), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ldy, target, ldt, (float*)grad, ldg, loss, npix, C, wn);
   else
-    hipLaunchKernelGGL(ce_kernel<bf16_t>, grid_for(npix), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ldy, target, ldt, (bf16_t*)grad, ldg, loss, npix, C, wn);
+    hipLaunchKernelGGL(ce_kernel<bf16_t>, grid_loss(npix), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ldy, target, ldt, (bf16_t*)grad, ldg, loss, npix, C, wn);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }
@@ -135,9 +143,9 @@ extern "C" int sdhip_l1_loss(const void* pred, const float* target, void* grad, 
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "l1_loss: unknown dtype %d", dtype);
   const float wn = weight / (float)n;
   if (dtype == SDHIP_F32)
-    hipLaunchKernelGGL(l1_kernel<float>, grid_for(n), dim3(256), 0, (hipStream_t)stream, (const float*)pred, target, (float*)grad, loss, n, wn);
+    hipLaunchKernelGGL(l1_kernel<float>, grid_loss(n), dim3(256), 0, (hipStream_t)stream, (const float*)pred, target, (float*)grad, loss, n, wn);
   else
-    hipLaunchKernelGGL(l1_kernel<bf16_t>, grid_for(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, target, (bf16_t*)grad, loss, n, wn);
+    hipLaunchKernelGGL(l1_kernel<bf16_t>, grid_loss(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, target, (bf16_t*)grad, loss, n, wn);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }

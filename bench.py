@@ -44,8 +44,8 @@ def parse():
 
 
 def build_model(dtype, name="minidsnetExt"):
-    from oracle.ref_models import CFG  # plain attribute bag (the argparse fields the model reads); no compute
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    CFG = N.CFG                                # plain attribute bag (the argparse fields the model reads)
     torch.manual_seed(0)
     if name == "dsnet":
         return N.dsnet(CFG(), labels=2, pretrained=False).cuda().train()
@@ -101,7 +101,7 @@ def cpu_baseline(B, H, W, steps, threads=16):
     """The CPU oracle (a port of the reference graph to plain torch.nn) on the host cores: fwd + loss + bwd."""
     import torch.nn.functional as F
     from oracle import ref_models as R
-    from pmt_learning_for_semantic_segmentation_and_disparity_amd.ops import _lovasz_softmax_torch
+    from oracle.losses_ref import lovasz_softmax_onehot as _lovasz_softmax_torch
     from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import synthetic_batch
     try:
         avail = len(os.sched_getaffinity(0))

@@ -293,7 +293,7 @@ class DenseNet(nn.Module):
         w0 = self.conv0.weight
         # The space-to-depth form sums the 147 products of an output in another order than the 7x7 form.  Exact in exact
         # arithmetic and at the f32 rounding level per output (2e-7), but train-mode BatchNorm over tiny batches amplifies
-        # any such reordering (tools/gpu_stem_diag.py), so the f32 parity path keeps the 7x7 form that the golden vectors
+        # any such reordering (tests/diag/gpu_stem_diag.py), so the f32 parity path keeps the 7x7 form that the golden vectors
         # were captured with; the bf16 throughput path takes the 2 % faster step.  SDHIP_STEM_S2D=0/1 forces either.
         s2d = os.environ.get("SDHIP_STEM_S2D")
         use_s2d = (x.dtype == torch.bfloat16) if s2d is None else s2d == "1"

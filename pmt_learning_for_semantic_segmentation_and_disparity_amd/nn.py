@@ -8,6 +8,17 @@ import torch.nn as nn
 from . import ops
 
 
+
+class CFG:
+    """The argparse fields the model constructors read (models/dsnet_t2.py:944-953: dropout, multaskloss, aspp, use_att,
+    hanet, convDeconvOut, abilation) as a plain attribute bag, for callers that do not carry the reference's argparse
+    namespace (bench.py, tools); any object with these attributes works."""
+
+    def __init__(self, dropout=0.0, multaskloss=0, aspp=0, use_att=1, hanet=0, convDeconvOut=0, abilation=''):
+        self.dropout, self.multaskloss, self.aspp, self.use_att = dropout, multaskloss, aspp, use_att
+        self.hanet, self.convDeconvOut, self.abilation = hanet, convDeconvOut, abilation
+
+
 class SpatialCorrelationSampler(nn.Module):
     """Replacement for `spatial_correlation_sampler.SpatialCorrelationSampler`
     as constructed at models/dsnet_t2.py:1078-1087: forward(input1, input2) ->

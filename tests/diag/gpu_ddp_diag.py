@@ -1,7 +1,7 @@
 """Per-parameter gradient difference: 2 ranks x 2 pairs (gloo, shared GPU) vs 1 rank x 4 pairs."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np, torch
 import torch.multiprocessing as mp
 from test_parallel import _gpu_rank_worker

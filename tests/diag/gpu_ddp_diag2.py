@@ -1,6 +1,6 @@
 """2 real ranks (gloo, one GPU) vs 1 rank: forward outputs per shard, then gradient w.r.t. the network outputs path."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

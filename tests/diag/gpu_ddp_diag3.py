@@ -1,6 +1,6 @@
 """One conv+BN+ReLU layer: 2 real ranks (gloo) vs 1 rank on the joint batch — output and gradient differences."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

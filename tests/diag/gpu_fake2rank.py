@@ -1,7 +1,7 @@
 """Multi-rank code paths on ONE process: world_size 2 with an all-reduce that doubles (both 'ranks' hold the same shard)
 vs one rank on the duplicated batch.  Per-module relative gradient differences."""
 import os, sys, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ref_models as R
 from oracle.detweights import fill_state_dict

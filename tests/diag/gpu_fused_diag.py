@@ -1,6 +1,6 @@
 """fused vs unfused BatchNorm paths on one rank: per-parameter gradient difference."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ref_models as R
 from oracle.detweights import fill_state_dict

@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pmt_learning_for_semantic_segmentation_and_disparity_amd.metrics import StepMetrics  # noqa: E402
 
 dev = torch.device("cuda:0")

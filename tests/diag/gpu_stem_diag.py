@@ -2,7 +2,7 @@
 form (SDHIP_STEM_S2D=1 / 0): shows that the deep, cancellation-dominated BatchNorm bias gradients move by the same amount
 under any change of the f32 summation order in the stem."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import ref_models as R
 from oracle.detweights import fill_state_dict, rand_input

@@ -93,7 +93,7 @@ def test_hip_densenet_backward_matches_oracle():
     x = rand_input(21, "img", (2, 3, 256, 256))
     wts = [rand_input(22, "g%d" % i, (1,)).item() + 0.5 for i in range(5)]
     # NB: with batch statistics over 2 x 8 x 8 values the deep BatchNorm gradients are cancellation-dominated: the f32
-    # oracle itself is up to 2.5 % (median 0.5 %) away from a float64 evaluation on these tensors (tools/gpu_stem_diag.py).
+    # oracle itself is up to 2.5 % (median 0.5 %) away from a float64 evaluation on these tensors (tests/diag/gpu_stem_diag.py).
     # The f32 path reproduces the oracle's conv0 output bit for bit and follows the same rounding history, hence 2e-2 holds.
     sum(w * (t * t).mean() for w, t in zip(wts, ref(x))).backward()
     sum(w * (t.float() * t.float()).mean() for w, t in zip(wts, mine(x.cuda()))).backward()

@@ -6,6 +6,7 @@ import torch
 
 from oracle import ref_models as R
 from oracle.detweights import fill_state_dict
+from oracle.losses_ref import lovasz_softmax_onehot
 
 
 def _model():
@@ -96,7 +97,7 @@ def test_train_loss_matches_reference_formulas(dtype, tol):
         seg1, seg2, disp = (t.bfloat16().float() for t in (seg1, seg2, disp))
     r = [t.clone().requires_grad_(True) for t in (seg1, disp, seg2)]
     ce = lambda y: torch.mean(torch.sum(-seg_t * F.log_softmax(y, 1), 1))
-    want = ce(r[0]) + ce(r[2]) + ops._lovasz_softmax_torch(r[2], seg_t) + F.l1_loss(r[1], disp_t)
+    want = ce(r[0]) + ce(r[2]) + lovasz_softmax_onehot(r[2], seg_t) + F.l1_loss(r[1], disp_t)
     want.backward()
     g = [t.cuda().to(dtype).requires_grad_(True) for t in (seg1, disp, seg2)]
     got = ops.train_loss(g[0], g[1], g[2], seg_t.cuda(), disp_t.cuda(), True)
@@ -120,7 +121,7 @@ def test_lovasz_single_class_present():
     zero = torch.zeros(B, 1, H, W)
     r = seg.clone().requires_grad_(True)
     ce = lambda y: torch.mean(torch.sum(-seg_t * F.log_softmax(y, 1), 1))
-    want = 2 * ce(r) + ops._lovasz_softmax_torch(r, seg_t)
+    want = 2 * ce(r) + lovasz_softmax_onehot(r, seg_t)
     want.backward()
     g1 = seg.cuda().requires_grad_(True); g2 = seg.cuda().requires_grad_(True)
     got = ops.train_loss(g1, zero.cuda().requires_grad_(True), g2, seg_t.cuda(), zero.cuda(), True)

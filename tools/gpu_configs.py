@@ -2,7 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle.ref_models import CFG
+from pmt_learning_for_semantic_segmentation_and_disparity_amd.nn import CFG
 from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N, ops
 from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
 

@@ -19,7 +19,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
 
 
 def parse():
@@ -38,6 +37,10 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the dominant-kernel microbenchmark (the command profiled under profiles/: tools/roofline_profile.sh)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (production).  gloo: rehearsal of the N-rank path on a box with fewer GPUs than ranks "
+                         "(ranks share devices, collectives go through the host; the number it prints is not a result)")
+    ap.add_argument("--rank-probe", action="store_true", help="each rank prints its launch environment and exits (CPU test of the launcher)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
     return ap.parse_args()
@@ -127,17 +130,59 @@ def cpu_baseline(B, H, W, steps, threads=16):
             "sample": "%d steps of B=%d %dx%d fp32 fwd+loss+bwd after 1 warm-up (oracle/ref_models.py)" % (steps, B, W, H)}
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` with no launcher environment: the parent starts N fresh rank processes (one per GPU,
+    the counterpart of mp.spawn(runNetwork, nprocs) at torch_implementation.py:975) and relays their output.  The parent
+    never touches the GPU (no torch import, no HIP call) and exits non-zero when any rank does."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live and not rc:
+        time.sleep(0.2)
+        for p in list(live):
+            if p.poll() is not None:
+                live.remove(p)
+                rc = rc or p.returncode
+    for p in live:   # one rank died: do not leave its peers hanging in a collective
+        p.kill()
+        p.wait()
+    sys.exit(rc)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (a.gpus, world))
+    if a.rank_probe:
+        print(json.dumps({"rank": rank, "local_rank": local, "world": world, "master": "%s:%s" % (
+            os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")), "pid": os.getpid(), "ppid": os.getppid()}), flush=True)
+        return
+    global torch
+    import torch
+    ndev = torch.cuda.device_count()
+    if a.backend == "nccl" and local >= ndev:
+        raise SystemExit("bench.py: rank %d needs GPU %d but this node shows %d (RCCL wants one GPU per rank)" % (rank, local, ndev))
+    torch.cuda.set_device(local % max(1, ndev))
     pg = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")   # RCCL on ROCm; MASTER_ADDR/PORT from the launcher env
+        dist.init_process_group(a.backend)   # "nccl" IS RCCL on ROCm; MASTER_ADDR/PORT from the launcher env
         pg = dist.group.WORLD
+        assert dist.get_world_size() == a.gpus
     from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     if a.roofline_only:
@@ -182,7 +227,9 @@ def main():
                                        if a.model == "dsnet" else
                                        "PSMNet(192) stacked hourglass train step fwd+loss(mean L1 x3)+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s")
                                       % (a.width, a.height, a.batch, "hipGraph" if step.use_graph else "eager"),
-                          "global_batch": a.batch * world, "parallelism": "dp%d" % world},
+                          "global_batch": a.batch * world, "parallelism": "dp%d" % world,
+                          "world_size": (torch.distributed.get_world_size() if world > 1 else 1),
+                          "backend": ("rccl" if a.backend == "nccl" else "gloo (rehearsal, not a result)") if world > 1 else None},
                "loss": round(lossv, 5)}
         sys.stderr.write("[bench] timed region done: %.3f ms/step\n" % (dt / a.steps * 1e3)); sys.stderr.flush()
         if not a.no_roofline:

@@ -42,6 +42,10 @@ extern "C" {
 int sdhip_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* sdhip_last_error(void);
+/* Diagnostic / tuning environment switches (SDHIP_CONV_GENERIC, SDHIP_TUNE_*, ... — DESIGN.md 7b) are read once when
+ * the library is loaded (a set switch is announced on stderr) and never per launch; a test or tool that changes the
+ * environment for an A/B run inside one process calls this to re-read them.  No reference counterpart. */
+void sdhip_diag_reload(void);
 
 /* ---------------------------------------------------------------------------
  * Spatial correlation sampler  (third-party op `SpatialCorrelationSampler`,

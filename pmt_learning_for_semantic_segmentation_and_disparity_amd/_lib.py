@@ -100,6 +100,28 @@ def packed_elems(M, K, T, dt):
     return _lib.sdhip_conv_packed_elems(M, K, T, dt)
 
 
+_lib.sdhip_diag_reload.restype = None
+
+
+def reload_diag():
+    """Re-read the SDHIP_* diagnostic environment switches (they are otherwise fixed at library load)."""
+    _lib.sdhip_diag_reload()
+
+
+def _diag_switch(name):
+    """Python-side diagnostic switches are read once, at import, and announced."""
+    v = os.environ.get(name)
+    if v:
+        import sys
+        sys.stderr.write("[sdhip] diagnostic switch %s=%s is set: this is not the production path\n" % (name, v))
+    return v
+
+
+DIAG_NO_FUSED_BN = bool(_diag_switch("SDHIP_DIAG_NO_FUSED_BN"))
+DIAG_NO_SIDE = bool(_diag_switch("SDHIP_DIAG_NO_SIDE"))
+DIAG_STEM_S2D = _diag_switch("SDHIP_STEM_S2D")
+
+
 def abi_version():
     return _lib.sdhip_abi_version()
 

@@ -570,7 +570,7 @@ Plan plan(int units, long npix_g, int G, int max_blocks = 2048) {
 }
 
 // workgroups of the consumer-side-finalize kernels: each one re-derives its coefficients from the replica sums (KBs from L2)
-int tune_fused_blocks() { static const int v = getenv("SDHIP_TUNE_FUSED_BLOCKS") ? atoi(getenv("SDHIP_TUNE_FUSED_BLOCKS")) : 768; return v; }
+int tune_fused_blocks() { return sdhip_diag().tune_fused_blocks; }
 
 int check_rows(const char* who, long npix, int C, int G, int dtype) {
   SDHIP_CHECK_ARG(npix > 0 && C > 0 && G >= 1 && npix % G == 0, "%s: bad shape npix=%ld C=%d groups=%d", who, npix, C, G);

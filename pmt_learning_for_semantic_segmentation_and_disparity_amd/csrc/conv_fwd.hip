@@ -454,11 +454,10 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   if ((long)kh * kw * kd * Cin <= 128 && a.Mpad <= 128) bn = a.Mpad > 64 ? 128 : (a.Mpad > 32 ? 64 : (a.Mpad > 16 ? 32 : 16));
   const int T = kh * kw;
   const long blocks_big = (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) * B * Do * sdhip_cdiv(a.Mpad, bn);
-  static const int tune_big = getenv("SDHIP_TUNE_BIG") ? atoi(getenv("SDHIP_TUNE_BIG")) : 512;
-  static const int tune_split = getenv("SDHIP_TUNE_SPLIT") ? atoi(getenv("SDHIP_TUNE_SPLIT")) : 1024;
-  static const int tune_ksoft_small = getenv("SDHIP_TUNE_KSOFT_SMALL") ? atoi(getenv("SDHIP_TUNE_KSOFT_SMALL")) : 80;
-  static const int tune_ksoft_big = getenv("SDHIP_TUNE_KSOFT_BIG") ? atoi(getenv("SDHIP_TUNE_KSOFT_BIG")) : 80;
-  bool big = (blocks_big >= tune_big && Wo >= 24) || getenv("SDHIP_CONV_BIG");
+  const SdhipDiag& dg = sdhip_diag();
+  const int tune_big = dg.tune_big, tune_split = dg.tune_split;
+  const int tune_ksoft_small = 80, tune_ksoft_big = 80;
+  bool big = (blocks_big >= tune_big && Wo >= 24) || dg.conv_big;
   if (!big) {
     // small feature maps (DenseNet blocks 2-4, pooled pyramids): the launch cannot fill 256 CUs with pixel tiles alone,
     // so split the output channels over more workgroups (the input tile is re-read from L2, the serial
@@ -475,7 +474,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   // ---- thin path (conv_thin.h): <= 8 input channels -> 1 output channel on the vector ALUs ----
   if (Cout == 1 && Cin <= V && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale &&
       !accumulate && kh * kw <= kThinMaxT && Ho == H + 2 * pad_t - dil * (kh - 1) && Wo == W + 2 * pad_l - dil * (kw - 1) &&
-      pad_t >= 0 && pad_l >= 0 && !getenv("SDHIP_CONV_NO_THIN")) {
+      pad_t >= 0 && pad_l >= 0 && !dg.conv_no_thin) {
     ThinArgs t;
     t.x = x; t.wp = wpacked; t.y = y; t.bias = bias; t.stats = stats;
     t.B = B; t.H = H; t.W = W; t.Ho = Ho; t.Wo = Wo; t.kh = kh; t.kw = kw; t.dil = dil; t.pad_t = pad_t; t.pad_l = pad_l;
@@ -489,7 +488,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   }
   // ---- fast path (conv_fast.h): 16-byte-aligned pixels on both sides, halo-tile mode ----
   if (!per_tap_any && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && a.vec_out &&
-      (long)H * W * ldx < (1L << 31) && !getenv("SDHIP_CONV_GENERIC")) {
+      (long)H * W * ldx < (1L << 31) && !dg.conv_generic) {
     const int ks = chunks_per_row == 4 ? 1 : 2;
     const int rb = 64 * ks, px_per_round = 256 / (4 * ks);
     FastArgs f;

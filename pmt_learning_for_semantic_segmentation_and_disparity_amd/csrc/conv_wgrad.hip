@@ -421,7 +421,7 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
   // ---- thin path (conv_thin.h): <= 8 input channels -> 1 output channel ----
   if (Cout == 1 && Cin <= V && a.vec_x && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale && T <= 25 &&
       Ho == H + 2 * pad_t - dil * (kh - 1) && Wo == W + 2 * pad_l - dil * (kw - 1) && pad_t >= 0 && pad_l >= 0 &&
-      !getenv("SDHIP_CONV_NO_THIN")) {
+      !sdhip_diag().conv_no_thin) {
     ThinWgArgs t;
     t.x = x; t.dy = dy; t.dwp = dw_packed; t.dbias = dbias;
     t.B = B; t.H = H; t.W = W; t.Ho = Ho; t.Wo = Wo; t.kh = kh; t.kw = kw; t.dil = dil; t.pad_t = pad_t; t.pad_l = pad_l;
@@ -431,13 +431,13 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
     {
       const int IHt = 8 + (kh - 1) * dil, IWt = 64 + (kw - 1) * dil, P = IWt + 2;
       const size_t lds = (size_t)IHt * P * 16 + 8 * 64 * 2;
-      static const bool no_tiled = getenv("SDHIP_THIN_WGRAD_REG") != nullptr;   // diagnostics: A/B against the register kernel
+      const bool no_tiled = sdhip_diag().thin_wgrad_reg;   // diagnostics: A/B against the register kernel
       if (dtype == SDHIP_BF16 && T > 9 && 8 * T <= 256 && lds <= 60 * 1024 && Wo >= 64 && Ho >= 8 && npix >= 65536 && !no_tiled) {
         const int th = sdhip_cdiv(Ho, 8), tw = sdhip_cdiv(Wo, 64);
         const int ntiles = B * th * tw;
         // measured at 8 x 256 x 512 (tools/gpu_thinwg.py): 128 / 256 / 512 / 1024 / 2048 workgroups -> 96 / 51 / 33 / 33 / 38 us:
         // the single-buffered tiles want several workgroups per CU; past 1024 the T x 8 flush atomics per workgroup show
-        static const int cap = getenv("SDHIP_TUNE_THIN_BLOCKS") ? atoi(getenv("SDHIP_TUNE_THIN_BLOCKS")) : 1024;
+        const int cap = sdhip_diag().tune_thin_blocks;
         const int blocks = ntiles < cap ? ntiles : cap;
         hipLaunchKernelGGL((conv_thin_wgrad_tiled_kernel<25>), dim3(blocks), dim3(256), lds, s, t, th, tw, IHt, IWt, P);
         SDHIP_LAUNCH_CHECK();
@@ -457,7 +457,7 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
   }
   // ---- bf16 fast path (conv_wgrad_fast.h): 16-byte-aligned pixels on both operands ----
   if (dtype == SDHIP_BF16 && a.vec_x && a.vec_dy && (long)H * W * ldx < (1L << 31) && (long)Ho * Wo * lddy < (1L << 31) &&
-      !getenv("SDHIP_WGRAD_GENERIC")) {
+      !sdhip_diag().wgrad_generic) {
     WgfArgs f;
     f.x = x; f.dy = dy; f.dwp = dw_packed; f.dbias = dbias; f.in_scale = in_scale; f.in_shift = in_shift;
     f.B = B; f.H = H; f.W = W; f.Ho = Ho; f.Wo = Wo; f.kh = kh; f.kw = kw; f.stride = stride; f.dil = dil; f.pad_t = pad_t; f.pad_l = pad_l;
@@ -468,13 +468,13 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
     if (T == 1 && a.tpb == 1) { f.tpb = 1; f.ntg = 1; }
     f.qb = 0; f.qsh = 0; f.nq_tot = a.nq;
     // 1x1 with many input channels (DenseNet bottlenecks / transitions): pack 2 or 4 channel chunks per workgroup
-    static const bool no_pack = getenv("SDHIP_WGRAD_NO_PACK") != nullptr;   // diagnostics: A/B against the unpacked kernel
+    const bool no_pack = sdhip_diag().wgrad_no_pack;   // diagnostics: A/B against the unpacked kernel
     // Measured (tools/gpu_wgrad1x1_ab.sh): it pays on large maps and wide outputs (192->128 at 16x64x128: 88 -> 52 us,
     // 1024->512 at 16x16x32: 62 -> 54 us); on the small maps of the deep DenseNet blocks the sweep is bound by the
     // per-tile DMA latency either way and the unpacked kernel's smaller tiles win (1024->128 at 16x16x32: 21 vs 31 us).
     const bool pack_pays = Cout >= 256 || (long)B * H * W >= 100000;
     if (T == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W && a.nq >= 2 && Cout > 32 && !no_pack &&
-        (pack_pays || getenv("SDHIP_WGRAD_FORCE_PACK"))) {
+        (pack_pays || sdhip_diag().wgrad_force_pack)) {
       WgfArgs g = f;
       g.qb = a.nq >= 3 ? 4 : 2; g.qsh = g.qb == 4 ? 2 : 1;
       g.kh = 1; g.kw = g.qb; g.tpb = g.qb; g.ntg = 1; g.nq = sdhip_cdiv(a.nq, g.qb);

@@ -453,7 +453,7 @@ int launch_wgf(const WgfArgs& a, hipStream_t s) {
   // Workgroups per (cout block, chunk, tap group): each one sweeps ntiles/gx tiles and then flushes its whole partial
   // sum with f32 atomics, which execute at the memory side at ~1.3 TB/s chip-wide.  On small feature maps the flush of
   // 256 workgroups costs more than their MFMAs: balance  (ntiles/gx) * t_tile  against  gx * flush bytes / 1.3 TB/s.
-  static const double tune_rate = getenv("SDHIP_TUNE_ATOMIC_TBS") ? atof(getenv("SDHIP_TUNE_ATOMIC_TBS")) : 1.3;
+  const double tune_rate = sdhip_diag().tune_atomic_tbs;
   const double t_tile_us = 0.35 + 0.17 * a.tpb;
   const double flush_us = (double)a.tpb * MB * 64 * 4 / (tune_rate * 1e6);
   int gx = (int)(sqrt((double)ntiles * t_tile_us / flush_us) + 0.5);

@@ -16,3 +16,37 @@ void sdhip_set_error(const char* fmt, ...) {
 
 extern "C" int sdhip_abi_version(void) { return SDHIP_ABI_VERSION; }
 extern "C" const char* sdhip_last_error(void) { return g_err; }
+
+// ---- diagnostic / tuning switches: read ONCE (library load), never per launch --------------------------------------
+// A stray environment variable must not silently change numerics mid-run: the table is filled at load, a set DIAG switch
+// is announced on stderr, and only an explicit sdhip_diag_reload() (tests / tools doing A/B runs in one process) re-reads it.
+static SdhipDiag g_diag;
+static bool g_diag_init = false;
+
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static bool env_set(const char* name) {
+  const char* v = getenv(name);
+  if (v && *v) { fprintf(stderr, "[libsdhip] diagnostic switch %s=%s is set: kernels / launch heuristics differ from production\n", name, v); return true; }
+  return false;
+}
+static void diag_fill() {
+  g_diag.conv_generic = env_set("SDHIP_CONV_GENERIC");
+  g_diag.conv_big = env_set("SDHIP_CONV_BIG");
+  g_diag.conv_no_thin = env_set("SDHIP_CONV_NO_THIN");
+  g_diag.wgrad_generic = env_set("SDHIP_WGRAD_GENERIC");
+  g_diag.wgrad_no_pack = env_set("SDHIP_WGRAD_NO_PACK");
+  g_diag.wgrad_force_pack = env_set("SDHIP_WGRAD_FORCE_PACK");
+  g_diag.thin_wgrad_reg = env_set("SDHIP_THIN_WGRAD_REG");
+  g_diag.tune_big = env_int("SDHIP_TUNE_BIG", 512);
+  g_diag.tune_split = env_int("SDHIP_TUNE_SPLIT", 1024);
+  g_diag.tune_thin_blocks = env_int("SDHIP_TUNE_THIN_BLOCKS", 1024);
+  g_diag.tune_fused_blocks = env_int("SDHIP_TUNE_FUSED_BLOCKS", 768);
+  g_diag.tune_atomic_tbs = getenv("SDHIP_TUNE_ATOMIC_TBS") ? atof(getenv("SDHIP_TUNE_ATOMIC_TBS")) : 1.3;
+  g_diag_init = true;
+}
+const SdhipDiag& sdhip_diag() {
+  if (!g_diag_init) diag_fill();
+  return g_diag;
+}
+__attribute__((constructor)) static void diag_at_load() { diag_fill(); }
+extern "C" void sdhip_diag_reload(void) { diag_fill(); }

@@ -27,6 +27,14 @@ void sdhip_set_error(const char* fmt, ...);
 #define SDHIP_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); \
     if (e__ != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "%s: launch failed: %s", __func__, hipGetErrorString(e__)); } while (0)
 
+// ---- diagnostic / tuning switches (runtime.hip): environment read once at library load ----
+struct SdhipDiag {
+  bool conv_generic, conv_big, conv_no_thin, wgrad_generic, wgrad_no_pack, wgrad_force_pack, thin_wgrad_reg;
+  int tune_big, tune_split, tune_thin_blocks, tune_fused_blocks;
+  double tune_atomic_tbs;
+};
+const SdhipDiag& sdhip_diag();
+
 // ---- bf16 <-> f32 ------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __builtin_bit_cast(float, ((unsigned int)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // RNE, NaN-safe (v_cvt_pk_bf16_f32)

@@ -54,9 +54,12 @@ def _he_init(mods):
             m.bias.data.zero_()
 
 
-def _no_dropout(p, training):
-    if p and training:
-        raise NotImplementedError("Dropout(p>0) in training mode is not on the native path yet (the shipped recipe uses p=0)")
+_dropout_ids = {}
+
+
+def _dropout_id(mod):
+    """Stable per-module stream id of a nn.Dropout (the mask is a function of (step seed, id, element index))."""
+    return _dropout_ids.setdefault(id(mod), 1000 + len(_dropout_ids))
 
 
 class conv2dSame(nn.Module):
@@ -147,9 +150,12 @@ def _act_block(block, p=0.0):
 
 
 def run_act_block(seq, x, residual=None, groups=1):
-    """Sequential(convbn|deconvbn, ReLU[, Dropout]) as one fused conv+BN+ReLU(+skip)."""
-    if len(seq) > 2:
-        _no_dropout(seq[2].p, seq.training)
+    """Sequential(convbn|deconvbn, ReLU[, Dropout]) as one fused conv+BN+ReLU(+skip).  With Dropout(p > 0) in training
+    mode (models/dsnet_t2.py:85-93; the shipped recipe has p = 0) the mask sits between the ReLU and the skip add, so the
+    skip is added after the dropout kernel instead of inside the BatchNorm pass."""
+    if len(seq) > 2 and seq[2].p and seq[2].training:
+        y = ops.dropout(seq[0].fused(x, act=1, groups=groups), seq[2].p, True, _dropout_id(seq[2]))
+        return y if residual is None else ops.add(y, residual)
     return seq[0].fused(x, act=1, residual=residual, groups=groups)
 
 
@@ -321,7 +327,6 @@ class minidsnetExt(nn.Module):
                     m.bias.data.zero_()
 
     def forward(self, input_a, input_b, pos=None, disp_gt=None, seg_gt=None):
-        _no_dropout(self.conv1d_at_d[2].p, self.training)
         B, _, H, W = input_a.shape
         # both images in one NHWC buffer, channels zero-padded 3 -> 8: one pixel = one 16-byte chunk, so the image convs
         # (conv0 7x7/2, conv2d_ba* 5x5 dil 2) stage their input with vector loads; the padded weight columns are zero.
@@ -372,9 +377,9 @@ class minidsnetExt(nn.Module):
             x3 = ops.interpolate(self.Conv2DownUp8(x1), size=s2.shape[2:])
             if self.use_att:
                 s2_d = self.Conv2DownUp7(ops.concat([s2, y3]))
-                at_d = self.conv1d_at_d[0].run(s2_d, act=2)
+                at_d = _seq_dropout(self.conv1d_at_d[2], self.conv1d_at_d[0].run(s2_d, act=2))
                 s2_s = self.Conv2DownUp9(ops.concat([s2, x3]))
-                at_s = self.conv1d_at_s[0].run(s2_s, act=2)
+                at_s = _seq_dropout(self.conv1d_at_s[2], self.conv1d_at_s[0].run(s2_s, act=2))
                 s2 = ops.concat([ops.mul_bcast(s2_d, at_s), ops.mul_bcast(s2_s, at_d)])
             else:
                 s2 = ops.concat([s2, x3, y3])
@@ -396,6 +401,10 @@ class minidsnetExt(nn.Module):
             if self.hanet:   # only on this branch, as upstream (models/dsnet_t2.py:1287-1289): with aspp == 2 the head is built but unused
                 seg2, _ = self.hanet_last(a[0], seg2, pos, attention_loss=True)
         return seg1, disp, seg2, disp
+
+
+def _seq_dropout(mod, x):
+    return ops.dropout(x, mod.p, mod.training, _dropout_id(mod)) if mod.p else x
 
 
 def _const(v, n, device):

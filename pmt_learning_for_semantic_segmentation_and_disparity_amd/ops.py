@@ -360,7 +360,7 @@ def _bn_finalize(stats, nrep, bn, count, groups, synced=False):
 
 def _fused_bn():
     """Consumer-side finalize kernels: single-GPU only (the sync-BN exchange sits between reduction and finalize)."""
-    return parallel.world_size() == 1 and not os.environ.get("SDHIP_DIAG_NO_FUSED_BN")
+    return parallel.world_size() == 1 and not _lib.DIAG_NO_FUSED_BN
 
 
 def _bn_track(bn, groups):
@@ -462,8 +462,6 @@ def wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale=None, in_shift=None, in_
     flat gradient buffer (StepContext.direct_grads).  With a StepContext side stream the launches go there: nothing
     downstream of a weight gradient runs before the optimizer, so it overlaps the latency-bound data-gradient chain."""
     c = _ctx[0]
-    if os.environ.get("SDHIP_DIAG_SKIP_WGRAD"):   # timing diagnostics only (tools/): gradients are left at zero
-        return None, None
     if c is not None and c.side is not None and c.direct_grads:
         main = torch.cuda.current_stream()
         c.side.wait_stream(main)                     # g and x are produced on the main stream
@@ -1038,11 +1036,21 @@ def train_loss(seg1, disp, seg2, seg_target, disp_target, use_lovasz=True):
 _rng = {"seed": None, "layers": 0}
 
 
+_RNG_BASE, _RNG_RANK_STRIDE = 0x5DEECE66D, 0x9E3779B97F4A7C15 >> 1
+
+
 def rng_seed_tensor(device):
-    """Device-resident dropout seed (advance it once per step: `ops.rng_seed_tensor(dev).add_(1)`)."""
+    """Device-resident dropout seed.  train.TrainStep advances it once per step with a device-side add (captured into the
+    step's hipGraph, so replays draw new masks); forward and backward of one step read the same value."""
     if _rng["seed"] is None or _rng["seed"].device != torch.device(device):
-        _rng["seed"] = torch.full((1,), 0x5DEECE66D, dtype=torch.int64, device=device)
+        _rng["seed"] = torch.full((1,), _RNG_BASE, dtype=torch.int64, device=device)
     return _rng["seed"]
+
+
+def rng_reseed(device, rank=0, base=_RNG_BASE):
+    """Restart the dropout stream; ranks of a data-parallel job get disjoint streams (in place: a captured graph keeps
+    reading the same tensor)."""
+    rng_seed_tensor(device).fill_((base + rank * _RNG_RANK_STRIDE) & 0x7FFFFFFFFFFFFFFF)
 
 
 class _DropoutFn(torch.autograd.Function):

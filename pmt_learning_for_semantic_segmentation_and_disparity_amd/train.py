@@ -51,7 +51,7 @@ class TrainStep:
         # sync-BN all-reduces per step — the weight gradients then run inside those waits.
         if use_side_stream is None:
             use_side_stream = world_size > 1
-        self.use_side_stream = use_side_stream and not os.environ.get("SDHIP_DIAG_NO_SIDE")   # env: timing diagnostics only
+        self.use_side_stream = use_side_stream and not _lib.DIAG_NO_SIDE   # timing diagnostics only
         self.graph = None
         self.static = None
         self.loss = None
@@ -59,7 +59,11 @@ class TrainStep:
         self.ctx = ops.StepContext(self.flat_p.device)
         self.ctx.nbt = []
         self.pack_desc = None
-        self.steps_done = 0
+        self.steps_done = 0       # optimizer steps actually EXECUTED (eager steps + graph replays; the recording pass of a capture runs nothing)
+        self._capture_fault = None   # tests: a callable invoked inside the capture to make it fail
+        # dropout streams differ per rank (the reference's ranks draw from independently seeded generators) and advance
+        # once per step on the device, so that graph replays see new masks (ops.rng_seed_tensor)
+        ops.rng_reseed(self.flat_p.device, rank=_rank_of(process_group) if world_size > 1 else 0)
 
     # -- pieces ---------------------------------------------------------------------------------
     def _arm(self):
@@ -112,7 +116,11 @@ class TrainStep:
             self._arm()
         elif self.nbt_tensors:
             torch._foreach_add_(self.nbt_tensors, self.nbt_incs)   # BatchNorm.num_batches_tracked, one launch
-        self.steps_done += 1
+        # next step draws new dropout masks.  A device-side add AFTER the backward pass (which regenerates this step's
+        # masks from the same seed): captured into the graph, so every replay advances it too.
+        ops.rng_seed_tensor(self.flat_p.device).add_(1)
+        if not torch.cuda.is_current_stream_capturing():
+            self.steps_done += 1
         return loss
 
     # -- public ---------------------------------------------------------------------------------
@@ -132,7 +140,19 @@ class TrainStep:
         mode = "thread_local" if self.world_size > 1 else "global"
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss = self._eager(*self.static)
+            if self._capture_fault is not None:
+                self._capture_fault()
         return self
+
+    def _abandon_capture(self):
+        """A capture that raised recorded launches but executed none: device state (parameters, moments, running
+        statistics, dropout seed) is that of the last eager warm-up step.  Only host-side bookkeeping of the half-recorded
+        step has to be reset before eager steps continue."""
+        self.graph, self.use_graph, self.loss = None, False, None
+        torch.cuda.synchronize()
+        self.ctx.unpacks = []
+        self.ctx.keep.clear()
+        ops.invalidate_packed_weights()
 
     def __call__(self, left, right, seg, disp):
         if not self.use_graph:
@@ -143,14 +163,19 @@ class TrainStep:
             except RuntimeError as e:   # e.g. a collective that cannot be captured on this RCCL build: run eagerly, loudly
                 import sys
                 sys.stderr.write("[TrainStep] hipGraph capture failed (%s); continuing WITHOUT a graph\n" % str(e).splitlines()[0])
-                self.graph, self.use_graph = None, False
-                torch.cuda.synchronize()
+                self._abandon_capture()
                 return self._eager(left, right, seg, disp)
         for dst, src in zip(self.static, (left, right, seg, disp)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        self.steps_done += 1
         return self.loss
+
+
+def _rank_of(pg):
+    import torch.distributed as dist
+    return dist.get_rank(pg) if dist.is_available() and dist.is_initialized() else 0
 
 
 def synthetic_batch(B, H, W, labels=2, device="cuda", seed=1234):

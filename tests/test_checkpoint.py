@@ -169,3 +169,31 @@ def test_resumed_train_step_continues_identically(tmp_path):
     assert abs(float(la) - float(lb)) <= 1e-4 * abs(float(la))
     rel = float((a.flat_p - b.flat_p).norm() / a.flat_p.norm())
     assert rel < 1e-5, rel
+
+
+@pytest.mark.gpu
+def test_graph_replays_are_counted_as_optimizer_steps(tmp_path):
+    """Adam's `step` written to the checkpoint = warm-up steps + graph replays (the recording pass of the capture runs
+    nothing and is not a step); a TrainStep resumed from that file continues like the one that wrote it."""
+    from oracle.detweights import fill_state_dict
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import checkpoint as C, nn as N, ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    batch = synthetic_batch(2, 256, 256)
+    mk = lambda seed: fill_state_dict(N.minidsnetExt(R.CFG(), labels=2, patch_type='1dcorr'), seed).cuda().train()
+    a = TrainStep(mk(5), dtype=torch.float32, use_graph=True)
+    n = 3
+    for _ in range(n):
+        a(*batch)                                  # first call: 2 eager warm-up steps + capture + 1 replay
+    assert a.steps_done == 2 + n
+    want_pow = torch.tensor([0.9 ** (2 + n), 0.999 ** (2 + n)])
+    assert torch.allclose(a.beta_pow.cpu(), want_pow, rtol=1e-5)
+    base = str(tmp_path / "ckg")
+    state = C.make_state(a, epoch=1)
+    assert all(int(v["step"]) == 2 + n for v in state["optimizer"]["state"].values())
+    C.save_checkpoint(state, 0.0, 0.5, 1.0, 0.5, base)
+    b = TrainStep(mk(6), dtype=torch.float32, use_graph=False)
+    C.load_checkpoint_and_params(base + ".pth.tar", b, map_location="cuda:0")
+    assert b.steps_done == 2 + n and torch.allclose(a.beta_pow, b.beta_pow, rtol=1e-6)
+    la, lb = a(*batch), b(*batch)
+    ops.set_step_context(None)
+    assert abs(float(la) - float(lb)) <= 2e-3 * max(1.0, abs(float(la)))

@@ -236,11 +236,12 @@ def test_hip_stem_space_to_depth_equals_7x7(dtype, tol, monkeypatch):
     """DenseNet stem (conv0 7x7/2 + norm0 + relu, models/densenet.py:222-225) in its space-to-depth form (4x4 stride-1 conv
     over the 2x2 space-to-depth image, the bf16 default) against the 7x7 form on the same kernels: raw tap, normalised
     output, and the gradients of conv0.weight / norm0 — f32: rounding-level agreement; bf16: bf16-level."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import _lib
     from pmt_learning_for_semantic_segmentation_and_disparity_amd.densenet import densenet121
     x = rand_input(21, "img", (4, 3, 64, 96)).cuda().to(dtype)
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("SDHIP_STEM_S2D", mode)
+        monkeypatch.setattr(_lib, "DIAG_STEM_S2D", mode)     # the switch is read once at import: set the cached value
         m = fill_state_dict(densenet121(), 21).cuda().train()
         taps = m(x, groups=2)
         (taps[0].float().pow(2).mean() + taps[1].float().pow(2).mean()).backward()

@@ -189,3 +189,69 @@ def test_gpu_two_ranks_match_one_rank_on_the_joint_batch():
         np.testing.assert_allclose(r[3], bn.running_mean.cpu().numpy(), rtol=1e-3, atol=1e-5)
         np.testing.assert_allclose(r[4], bn.running_var.cpu().numpy(), rtol=1e-3, atol=1e-5)
     assert np.array_equal(res[0][2], res[1][2])      # both ranks hold the same reduced gradient
+
+
+def _nccl_rank_worker(rank, world, port, q):
+    """One RCCL rank on its own GPU: two warm-up steps, hipGraph capture with the sync-BN and gradient all-reduces inside,
+    one replay — then the same state again without a graph."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from oracle import ref_models as R
+    from oracle.detweights import fill_state_dict
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    full = synthetic_batch(4, 256, 256, seed=77, device="cpu")
+    shard = [t[rank * 2:(rank + 1) * 2].contiguous().cuda() for t in full]
+    out = {}
+    for graph in (True, False):
+        m = fill_state_dict(N.minidsnetExt(R.CFG(aspp=0), labels=2, patch_type='1dcorr'), 51).cuda().train()
+        step = TrainStep(m, dtype=torch.float32, use_graph=graph, use_lovasz=False, lr=1e-4, world_size=world,
+                         process_group=dist.group.WORLD)
+        losses = [float(step(*shard)) for _ in range(1 if graph else 3)]      # graph: first call = 2 warm-ups + capture + replay
+        torch.cuda.synchronize()
+        out[graph] = (losses[-1], step.use_graph, step.flat_p.detach().cpu().numpy())
+        dist.barrier()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: 2 GPUs")
+def test_rccl_two_ranks_train_step_graph_and_eager():
+    """backend 'nccl' (= RCCL) with world size 2 (torch_implementation.py:629,739-741): the captured step (394 sync-BN
+    all-reduces + the flat gradient all-reduce inside one hipGraph) reproduces the eager step, both ranks end with the same
+    parameters, and the loss mean equals the single-rank loss on the joint batch."""
+    import numpy as np
+    res = _spawn2(_nccl_rank_worker, 29500 + (os.getpid() % 400))
+    for r in res:
+        g, e = r[1][True], r[1][False]
+        assert g[1] is True, "hipGraph capture of the RCCL step fell back to eager"
+        assert abs(g[0] - e[0]) <= 2e-3 * max(1.0, abs(e[0]))
+        assert np.linalg.norm(g[2] - e[2]) <= 1e-3 * np.linalg.norm(e[2])
+    assert np.array_equal(res[0][1][False][2], res[1][1][False][2])      # ranks stay in lock step
+    assert np.array_equal(res[0][1][True][2], res[1][1][True][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_two_rank_launch_rehearsal():
+    """The command the driver runs for N > 1 (`python bench.py --gpus 2 ...`) starts two ranks, trains, and rank 0 prints ONE
+    JSON line with n_gpus 2 / dp2.  On the one-GPU test box the two ranks share the device and use gloo (RCCL refuses two
+    ranks per device); with >= 2 GPUs the same command runs on RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--height", "256", "--width", "256", "--backend", backend, "--no-cpu-baseline", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 1, r.stdout
+    j = rows[0]
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["world_size"] == 2
+    assert j["config"]["global_batch"] == 4 and j["value"] > 0 and j["scaling"] == "weak"

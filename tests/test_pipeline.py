@@ -69,3 +69,32 @@ def test_files_to_checkpoint_round_trip(tmp_path):
     ops.set_step_context(None)
     assert start == 1 and ehist == [1] and best == [1.0, round(out["pixelAcc"], 4)]
     assert torch.equal(fresh.flat_p, ts.flat_p) and fresh.steps_done == 3
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus N` with no launcher environment starts N rank processes itself (the counterpart of
+    mp.spawn(runNetwork, nprocs), torch_implementation.py:975) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set;
+    under a launcher (WORLD_SIZE present) it does not spawn again, and a --gpus / WORLD_SIZE mismatch is an error."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rank-probe"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(x["rank"] for x in rows) == [0, 1, 2] and all(x["world"] == 3 for x in rows)
+    assert all(x["rank"] == x["local_rank"] for x in rows)
+    assert len({x["master"] for x in rows}) == 1 and rows[0]["master"].startswith("127.0.0.1:")
+    assert len({x["pid"] for x in rows}) == 3 and len({x["ppid"] for x in rows}) == 1
+    # launched by torch.distributed.run (the driver's N > 1 command): the rank runs in place
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rank-probe"],
+                       env=dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"),
+                       capture_output=True, text=True, timeout=120)
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(rows) == 1 and rows[0]["rank"] == 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--rank-probe"],
+                       env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr

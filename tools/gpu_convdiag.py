@@ -22,6 +22,7 @@ for (B, H, W, Cin, Cout, k, dil) in SHAPES:
     for gen in ("1", ""):
         if gen: os.environ["SDHIP_CONV_GENERIC"] = gen
         else: os.environ.pop("SDHIP_CONV_GENERIC", None)
+        __import__("pmt_learning_for_semantic_segmentation_and_disparity_amd")._lib.reload_diag()
         for _ in range(3): go()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

@@ -243,14 +243,18 @@ int sdhip_adam_step(float* params, const float* grads, float* exp_avg, float* ex
  * logits: categoricalCrossEntropy(F.log_softmax(y,1), gt) of util/utilTorchLoss.py:373-378.  target is f32. */
 int sdhip_ce_loss(const void* logits, int ldy, const float* target, int ldt, void* grad, int ldg, double* loss,
                   long npix, int C, float weight, int dtype, void* stream);
-/* loss += weight * mean |pred - target| (nn.L1Loss, losses/multiLosses.py:141) and its gradient. */
+/* loss += weight * mean |pred - target| (nn.L1Loss, losses/multiLosses.py:141) and its gradient.  mask_nonpositive != 0:
+ * elements whose target is <= 0 contribute zero but stay in the mean — L1(pred*zeros, disp*zeros) with zeros = disp > 0,
+ * the cityscapes / kitti rule of losses/multiLosses.py:134-141. */
 int sdhip_l1_loss(const void* pred, const float* target, void* grad, double* loss, long n, float weight,
-                  int dtype, void* stream);
+                  int mask_nonpositive, int dtype, void* stream);
 /* y = x * mask / (1-p), mask from a counter-based hash of (*seed, layer_id, element index): applying the same call to
  * the gradient is the backward pass (nn.Dropout(0.5) of models/aspp.py:79,95).  x/y: dense buffers of n elements. */
 int sdhip_dropout(const void* x, void* y, const long* seed, long layer_id, long n, float p, int dtype, void* stream);
-/* Lovasz-softmax (util/lovasz_losses.py:153-199: classes='present', per_image=False, ignore=None) on
- * softmax(logits) with labels = argmax(target one-hot), as called at losses/multiLosses.py:70-72.
+/* Lovasz-softmax (util/lovasz_losses.py:153-199: classes='present', per_image=False) on
+ * softmax(logits) with labels = argmax(target one-hot), as called at losses/multiLosses.py:70-72.  A pixel whose target
+ * row has no positive entry is void and removed from the loss (`ignore=19` with the 20th one-hot channel dropped,
+ * losses/multiLosses.py:19-21; flatten_probas, util/lovasz_losses.py:202-216).
  * loss += weight * mean_{present c} dot(sort_desc |fg_c - p_c|, lovasz_grad(fg sorted)); grad (if non-NULL) is
  * ACCUMULATED (+=) with the gradient w.r.t. the logits.  workspace: sdhip_lovasz_workspace_bytes(npix, C) bytes. */
 long sdhip_lovasz_workspace_bytes(long npix, int C);

@@ -9,6 +9,12 @@ def lovasz_softmax_onehot(logits, labels_onehot):
     B, C, H, W = logits.shape
     p = torch.softmax(logits.float(), 1).permute(0, 2, 3, 1).reshape(-1, C)
     fg_all = labels_onehot.permute(0, 2, 3, 1).reshape(-1, C)
+    # void pixels (no positive entry in the one-hot row: `ignore=19` after the 20th channel is dropped,
+    # losses/multiLosses.py:19-21) are removed before anything else (flatten_probas, util/lovasz_losses.py:202-216)
+    valid = fg_all.max(1).values > 0
+    p, fg_all = p[valid], fg_all[valid]
+    if p.numel() == 0:
+        return logits.sum() * 0.0
     total = p.new_zeros(())
     present = p.new_zeros(())
     for c in range(C):
@@ -27,3 +33,15 @@ def lovasz_softmax_onehot(logits, labels_onehot):
     return total / present.clamp_min(1.0)
 
 
+
+
+def train_loss_ref(seg1, disp, seg2, seg_t, disp_t, use_lovasz=True, mask_invalid_disp=False):
+    """The loss of the timed step: CE(seg1) + CE(seg2) [+ Lovasz(seg2)] + L1(disp)
+    (torch_implementation.py:279,293,304,325; losses/multiLosses.py:66-72,134-141; util/utilTorchLoss.py:373-378)."""
+    import torch.nn.functional as F
+    ce = lambda y: torch.mean(torch.sum(-seg_t * F.log_softmax(y.float(), 1), 1))
+    z = (disp_t > 0).float() if mask_invalid_disp else 1.0
+    loss = ce(seg1) + ce(seg2) + F.l1_loss(disp.float() * z, disp_t * z)
+    if use_lovasz:
+        loss = loss + lovasz_softmax_onehot(seg2, seg_t)
+    return loss

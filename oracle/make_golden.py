@@ -40,6 +40,11 @@ def _install_stubs():
     for sub in ("models", "transforms", "datasets"):
         setattr(sys.modules["torchvision"], sub, sys.modules["torchvision." + sub])
     sys.modules["cv2"].imwrite = lambda *a, **k: True   # GetSegMetricsNp / GetDispMetricsNp dump JPEGs; not part of the results
+    tvf = types.ModuleType("torchvision.transforms.functional")   # util/utilTorchGate.py:38 imports `pad` (edge losses: not on this path)
+    tvf.pad = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("torchvision stub"))
+    sys.modules["torchvision.transforms"].__path__ = []
+    sys.modules.setdefault("torchvision.transforms.functional", tvf)
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
     eff = types.ModuleType("efficientnet_pytorch")
     eff.EfficientNet = type("EfficientNet", (), {})
     sys.modules["efficientnet_pytorch"] = eff
@@ -463,15 +468,209 @@ def gen_dsnet():
     save("dsnet", **arrays)
 
 
+def gen_losses():
+    """The reference's own loss functions (losses/multiLosses.py lossSeg_fn / lossDisp_fn, util/lovasz_losses.py) on small
+    stored inputs: value and gradient w.r.t. the network outputs.  `cross_entropy lovasz_loss` is the shipped recipe
+    (scripts/trainTorchImpl.sh:34); cityscapes adds the ignore channel and the disp > 0 mask."""
+    import warnings
+    from losses import multiLosses as ML
+    from util import lovasz_losses as LV
+    rng = np.random.default_rng(5)
+    arrays = {}
+    cases = [("roses", "roses", 2, 2, 2, 32, 32, None), ("garden_absent", "garden", 5, 5, 2, 16, 24, 3),
+             ("city", "cityscapes", 19, 20, 2, 24, 32, 7), ("city_allvoid_class", "cityscapes", 19, 20, 1, 8, 8, None)]
+    for name, ds, L, Ct, B, H, W, absent in cases:
+        logits = rng.normal(0, 2, (B, L, H, W)).astype(np.float32)
+        cls = rng.integers(0, Ct, (B, H, W))
+        if absent is not None:
+            cls[cls == absent] = (absent + 1) % L
+        if name == "city_allvoid_class":
+            cls[:] = 19                      # only void pixels: the Lovasz term and its gradient are zero
+            cls[0, 0, :3] = [1, 1, 4]
+        seg_full = np.eye(Ct, dtype=np.float32)[cls].transpose(0, 3, 1, 2).copy()
+        disp = (rng.uniform(0, 8, (B, 1, H, W)) * (rng.uniform(0, 1, (B, 1, H, W)) > (0.3 if ds == "cityscapes" else -1))).astype(np.float32)
+        disp_pred = (disp + rng.normal(0, 1.0, disp.shape)).astype(np.float32)
+        cfg = types.SimpleNamespace(datasetName=ds, segWeight=0, outputType='segDisp')
+        for tag, loss_type in (("ce_lovasz", ['cross_entropy', 'lovasz_loss']), ("ce", ['cross_entropy']), ("lovasz", ['lovasz_loss'])):
+            # (copies: lossSeg_fn's metric block edits `seg_pred.detach().cpu().numpy()` in place, which on the CPU aliases the input)
+            y = torch.from_numpy(logits.copy()).requires_grad_(True)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out = ML.lossSeg_fn(loss_type, torch.from_numpy(seg_full.copy()), y, cfg, 0)
+            loss = out[2]
+            loss.backward()
+            arrays["%s.%s.loss" % (name, tag)] = np.float64(loss.item())
+            arrays["%s.%s.grad" % (name, tag)] = y.grad.numpy().copy()
+        d = torch.from_numpy(disp_pred.copy()).requires_grad_(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = ML.lossDisp_fn([], None, torch.from_numpy(seg_full.copy()), torch.from_numpy(disp.copy()), d, 192.0, cfg, 0)
+        out[2].backward()
+        arrays["%s.l1.loss" % name] = np.float64(out[2].item())
+        arrays["%s.l1.grad" % name] = d.grad.numpy().copy()
+        # the Lovasz extension on its own (util/lovasz_losses.py:153-168), all three `classes` modes the function offers
+        y = torch.from_numpy(logits.copy())
+        lab = torch.from_numpy(cls.copy())
+        ign = None if ds in ("roses", "garden") else 19
+        arrays["%s.lovasz_present" % name] = np.float64(float(LV.lovasz_softmax(F.softmax(y, 1), lab, ignore=ign)))
+        arrays.update({"%s.logits" % name: logits, "%s.seg_full" % name: seg_full, "%s.disp" % name: disp,
+                       "%s.disp_pred" % name: disp_pred, "%s.labels" % name: np.int64(L)})
+        arrays["%s.dataset" % name] = np.array(ds)
+        # the oracle restatement must agree here and now
+        from oracle.losses_ref import train_loss_ref
+        seg_t = torch.from_numpy(seg_full[:, :L])
+        y1 = torch.from_numpy(logits).requires_grad_(True)
+        dd = torch.from_numpy(disp_pred).requires_grad_(True)
+        zero = torch.zeros_like(y1)
+        mine = train_loss_ref(y1, dd, y1, seg_t, torch.from_numpy(disp), True, ds == "cityscapes")   # CE counted twice
+        want = 2 * arrays["%s.ce.loss" % name] + arrays["%s.lovasz.loss" % name] + arrays["%s.l1.loss" % name]
+        assert abs(float(mine) - want) < 1e-5 * max(1.0, abs(want)), (name, float(mine), want)
+        mine.backward()
+        gw = 2 * arrays["%s.ce.grad" % name] + arrays["%s.lovasz.grad" % name]
+        assert float((y1.grad - torch.from_numpy(gw)).abs().max()) < 1e-6, name
+        assert abs(arrays["%s.ce_lovasz.loss" % name] - arrays["%s.ce.loss" % name] - arrays["%s.lovasz.loss" % name]) < 1e-5, name
+        assert float((dd.grad - torch.from_numpy(arrays["%s.l1.grad" % name])).abs().max()) < 1e-7, name
+        print("losses", name, "oracle==reference", want)
+    save("losses", **arrays)
+
+
+def gen_dsnetnocorr():
+    from models import dsnet_t2 as D
+    arrays = {}
+    for mode in ("train", "eval"):
+        ref = fill_state_dict(D.dsnetnoCorr(R.CFG(), labels=2, pretrained=False), 71)
+        ref.train() if mode == "train" else ref.eval()
+        a, b = rand_input(71, "left", (2, 3, 256, 256)), rand_input(71, "right", (2, 3, 256, 256))
+        seg = F.one_hot((rand_input(71, "seg", (2, 256, 256)) > 0.5).long(), 2).permute(0, 3, 1, 2).float()
+        disp = rand_input(71, "disp", (2, 1, 256, 256), 0.0, 8.0)
+        outs = ref(a, b)
+        loss = torch.mean(torch.sum(-seg * outs[0], 1)) + torch.mean(torch.sum(-seg * outs[2], 1)) + F.l1_loss(outs[1], disp) + F.l1_loss(outs[3], disp)
+        loss.backward()
+        p = "dsnetnocorr.%s" % mode
+        for i, name in enumerate(("seg1", "disp", "seg2", "disp2")):
+            arrays.update(flat("%s.%s" % (p, name), sample(outs[i], 8)))
+        arrays["%s.loss" % p] = np.float64(loss.item())
+        for k, v in grad_norms(ref).items():
+            arrays["%s.gnorm.%s" % (p, k)] = v
+        mine = R.dsnetnoCorr(R.CFG(), labels=2)
+        mine.load_state_dict(fill_state_dict(D.dsnetnoCorr(R.CFG(), labels=2, pretrained=False), 71).state_dict() if mode == "train" else ref.state_dict())
+        mine.train() if mode == "train" else mine.eval()
+        for x, y in zip(mine(a, b), outs):
+            err = float((x - y).abs().max())
+            assert err < 2e-4 * max(1.0, float(y.abs().max())), (mode, err)
+        print("dsnetnoCorr", mode, "oracle==reference, loss", loss.item())
+    save("dsnetnocorr", **arrays)
+
+
+def gen_syncbn():
+    """Statistics maths of synchronised BatchNorm on split batches: the reference's vendored `_compute_mean_std`
+    (sync_batchnorm/batchnorm.py:114-126; dead code upstream but named by SURVEY 8c as the semantics statement) and the
+    live path's torch BatchNorm on the joint batch (nn.SyncBatchNorm, torch_implementation.py:739)."""
+    from sync_batchnorm.batchnorm import SynchronizedBatchNorm2d
+    arrays = {}
+    for name, B, C, H, W, parts in (("two_ranks", 4, 6, 5, 7, 2), ("four_ranks_tiny", 8, 3, 1, 2, 4)):
+        x = randn_input(81, name, (B, C, H, W)) * 2.0 + 0.5
+        bn = SynchronizedBatchNorm2d(C)
+        bn.running_mean = randn_input(82, name + "rm", (C,))
+        bn.running_var = rand_input(82, name + "rv", (C,), 0.5, 2.0)
+        rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+        shards = x.chunk(parts, 0)
+        sums = [(s.sum((0, 2, 3)), (s * s).sum((0, 2, 3)), s.numel() // C) for s in shards]      # what every replica sends (:62-64)
+        sum_ = sum(t[0] for t in sums); ssum = sum(t[1] for t in sums); size = sum(t[2] for t in sums)
+        mean, inv_std = bn._compute_mean_std(sum_, ssum, size)
+        ref = torch.nn.BatchNorm2d(C)
+        ref.running_mean.copy_(rm0); ref.running_var.copy_(rv0)
+        y = ref.train()(x)
+        arrays.update(flat(name, dict(x=x.numpy(), parts=np.int64(parts), rm0=rm0.numpy(), rv0=rv0.numpy(),
+                                      mean=mean.numpy(), inv_std_clamp=inv_std.numpy(), rm_sync=bn.running_mean.numpy().copy(),
+                                      rv_sync=bn.running_var.numpy().copy(), y_joint=y.detach().numpy(),
+                                      rm_joint=ref.running_mean.numpy().copy(), rv_joint=ref.running_var.numpy().copy())))
+        assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-6) and torch.allclose(bn.running_var, ref.running_var, atol=1e-5)
+    save("syncbn", **arrays)
+
+
+def gen_cfg5():
+    """BASELINE config 5's network — minidsnetExt(aspp=2, hanet=1, labels=19) — and the (aspp=0, hanet=1, labels=19) variant
+    in which the HANet head is actually applied (models/dsnet_t2.py:1287-1289), eval mode (ASPP Dropout(0.5) and HANet
+    Dropout2d(0.1) are stochastic in train mode), with the cityscapes loss rule (void class, disp > 0 mask) and its
+    gradients through the eval-mode network."""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from models import dsnet_t2 as D
+    from oracle.losses_ref import train_loss_ref
+    arrays = {}
+    for tag, kw in (("a2_hanet_l19", dict(aspp=2, hanet=1)), ("a0_hanet_l19", dict(aspp=0, hanet=1))):
+        cfg = R.CFG(**kw)
+        ref = fill_state_dict(D.minidsnetExt(cfg, labels=19, pretrained=False, patch_type='1dcorr', backbone='densenet'), 91)
+        a, b = rand_input(91, "left", (2, 3, 256, 256)), rand_input(91, "right", (2, 3, 256, 256))
+        pos = _pos(2, 256, 256)
+        # running statistics as after training (batch statistics of this input; dropouts off while they are collected),
+        # stored in the fixture: random running statistics blow the activations up through ~120 layers (loss ~ 1e4)
+        bns = [m for m in ref.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        drops = [m for m in ref.modules() if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d))]
+        keep_p = [m.p for m in drops]
+        for m in bns:
+            m.reset_running_stats(); m.momentum = None
+        for m in drops:
+            m.p = 0.0
+        ref.train()
+        with torch.no_grad():
+            ref(a, b, pos)
+        for m in bns:
+            m.momentum = 0.1
+        for m, pp in zip(drops, keep_p):
+            m.p = pp
+        ref.eval()
+        for k, v in ref.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                arrays["%s.state.%s" % (tag, k)] = v.numpy().astype(np.float32).copy()
+        cls = (rand_input(91, "cls", (2, 256, 256)) * 20).long().clamp(0, 19)           # 19 = void
+        seg = F.one_hot(cls, 20).permute(0, 3, 1, 2).float()[:, :19].contiguous()
+        disp = rand_input(91, "disp", (2, 1, 256, 256), 0.0, 8.0) * (rand_input(91, "dmask", (2, 1, 256, 256)) > 0.3).float()
+        outs = ref(a, b, pos)
+        loss = train_loss_ref(outs[0], outs[1], outs[2], seg, disp, True, True)
+        loss.backward()
+        for i, name in enumerate(("seg1", "disp", "seg2")):
+            arrays.update(flat("%s.eval.%s" % (tag, name), sample(outs[i], 8)))
+        arrays["%s.eval.loss" % tag] = np.float64(loss.item())
+        for k, v in grad_norms(ref).items():
+            arrays["%s.eval.gnorm.%s" % (tag, k)] = v
+        mine = R.minidsnetExt(cfg, labels=19, patch_type='1dcorr')
+        mine.load_state_dict(ref.state_dict())
+        mine.eval()
+        with torch.no_grad():
+            mo = mine(a, b, pos)
+        for x_, y_ in zip(mo, outs):
+            assert float((x_ - y_).abs().max()) < 2e-4 * max(1.0, float(y_.abs().max())), tag
+        print("cfg5", tag, "oracle==reference, loss", loss.item())
+    arrays["meta.corr"] = np.array("assumed-semantics")
+    save("cfg5", **arrays)
+
+
 def gen_psmnet():
     import importlib
     SH = importlib.import_module("models_psmnet.stackhourglass")   # (the package re-exports the class under this name)
     arrays = {}
     for mode in ("train", "eval"):
         ref = fill_state_dict(SH.PSMNet(64), 41)
-        ref.train() if mode == "train" else ref.eval()
         a, b = rand_input(41, "left", (2, 3, 256, 256)), rand_input(41, "right", (2, 3, 256, 256))
         disp = rand_input(41, "disp", (2, 256, 256), 0.0, 40.0)
+        if mode == "eval":
+            # running statistics of a trained network, not random ones (random statistics saturate the softmax over
+            # disparities and make the eval prediction a step function of 1e-6 cost differences): one train-mode forward
+            # with cumulative-average momentum sets them to the batch statistics of this input; they are stored.
+            bns = [m for m in ref.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+            for m in bns:
+                m.reset_running_stats()
+                m.momentum = None
+            ref.train()
+            with torch.no_grad():
+                ref(a, b)
+            for m in bns:
+                m.momentum = 0.1
+            for k, v in ref.state_dict().items():
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    arrays["psm64.eval.state.%s" % k] = v.numpy().copy()
+        ref.train() if mode == "train" else ref.eval()
         outs = ref(a, b)
         outs = outs if isinstance(outs, tuple) else (outs,)
         loss = sum(F.l1_loss(o, disp) for o in outs) / len(outs)   # build-defined PSMNet loss: mean L1 of the predictions
@@ -498,7 +697,15 @@ if __name__ == "__main__":
     _install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet", "hanet", "metrics", "keys", "data"]
+    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet", "hanet", "metrics", "keys", "data", "losses", "dsnetnocorr", "syncbn", "cfg5"]
+    if "losses" in which:
+        gen_losses()
+    if "syncbn" in which:
+        gen_syncbn()
+    if "cfg5" in which:
+        gen_cfg5()
+    if "dsnetnocorr" in which:
+        gen_dsnetnocorr()
     if "ops" in which:
         gen_ops()
     if "backbone" in which:

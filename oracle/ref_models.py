@@ -708,6 +708,7 @@ class PSMNet(nn.Module):
 class dsnet(nn.Module):
     """models/dsnet_t2.py:119-321 — the line-for-line PyTorch port of the TF baseline_SDnet_small_fixed graph
     (2-D 17x17 correlation, stride-2 transposed convs in the segmentation decoder)."""
+    _no_corr = False
 
     def __init__(self, CFG, labels=8, pretrained=False, backbone='densenet'):
         super().__init__()
@@ -715,7 +716,7 @@ class dsnet(nn.Module):
         for j in (1, 2, 3):
             setattr(self, 'conv2d_ba%d' % j, _img_conv(3))
         self.correlation_sampler = SpatialCorrelationSampler(1, (17, 17), 1, 0, dilation_patch=1)
-        self.corrConv2d = _c1x1(289, 128)
+        self.corrConv2d = _c1x1(512 if self._no_corr else 289, 128)
         self.conv1d_1 = _c1x1(2048, 64)
         self.Conv2DownUp1 = Conv2DownUp(64, 32, 3)
         self.Conv2DownUp2 = nn.Sequential(Conv2DownUp(32, 32, 3, lastLayer=False), ConvTranspose2dSame(32, labels, 3, 1, padding='same', init_he=False))
@@ -750,9 +751,12 @@ class dsnet(nn.Module):
         x1 = F.interpolate(x, scale_factor=2, mode='nearest')
         seg1 = F.interpolate(self.Conv2DownUp2(x1), scale_factor=8, mode='nearest')
         seg1 = F.log_softmax(F.interpolate(seg1, size=size, mode='bilinear'), 1)
-        y = self.correlation_sampler(a[5], b[5])
-        n, ph, pw, h, w = y.shape
-        y = self.corrConv2d(y.reshape(n, ph * pw, h, w) / a[5].size(1))
+        if self._no_corr:      # dsnetnoCorr (models/dsnet_t2.py:697-700): concatenated tap-2 maps instead of the correlation
+            y = self.corrConv2d(torch.cat((a[2], b[2]), 1))
+        else:
+            y = self.correlation_sampler(a[5], b[5])
+            n, ph, pw, h, w = y.shape
+            y = self.corrConv2d(y.reshape(n, ph * pw, h, w) / a[5].size(1))
         y1 = F.interpolate(self.Conv2DownUp3(x1), size=y.shape[2:], mode='bilinear')
         y = self.Conv2DownUp4(torch.cat((y1, y), 1))
         y2 = F.interpolate(y, scale_factor=8)
@@ -784,3 +788,11 @@ class dsnet(nn.Module):
         d2 = self.Conv2DownUp10(self.conv1d_8(torch.cat((y, xl3), 1)))
         d2 = F.interpolate(d2, size, mode='bilinear')
         return seg1, disp, seg2, 0.8 * d2 + 0.2 * disp
+
+
+class dsnetnoCorr(dsnet):
+    """models/dsnet_t2.py:620-823 — PyTorch port of the TF baseline_SDnet_small graph: dsnet without the correlation."""
+    _no_corr = True
+
+    def __init__(self, CFG, labels=8, pretrained=False):
+        super().__init__(CFG, labels=labels, pretrained=pretrained)

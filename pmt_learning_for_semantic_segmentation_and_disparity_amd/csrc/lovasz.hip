@@ -1,9 +1,13 @@
-// Lovasz-softmax loss (util/lovasz_losses.py:153-199 with classes='present', per_image=False, ignore=None, applied to
+// Lovasz-softmax loss (util/lovasz_losses.py:153-199 with classes='present', per_image=False, applied to
 // softmax(log_softmax(logits)) = softmax(logits) and labels = argmax(one-hot), losses/multiLosses.py:70-72), forward
 // value and gradient w.r.t. the logits in one call.  HBM bound: per class one descending radix sort of (|fg - p|, index)
 // over all B*H*W pixels (rocPRIM device primitives), an inclusive scan of the sorted foreground flags, and two
 // elementwise passes.  The Jaccard gradient is a constant w.r.t. the errors (as in the reference, which detaches it),
 // so d loss / d p_c[i] = -sign(fg - p) * lovasz_grad(fg_sorted)[rank(i)].
+// ignore=<void label> (flatten_probas :202-216; cityscapes: losses/multiLosses.py:19-21 drops the 20th one-hot channel and
+// passes ignore=19): a pixel whose target row has no positive entry is VOID.  Void pixels get the key -1 (every real error
+// is >= 0), so the descending sort parks them behind the nvalid real entries; the Jaccard walk stops at nvalid and they
+// receive no gradient — the same as removing them from the flattened arrays.
 #include "sdhip_common.h"
 #include <cstring>
 #include <string.h>
@@ -24,7 +28,9 @@ __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict_
   // per-class pixel counts: LDS histogram per workgroup, one global atomic per class per workgroup (a global atomic per
   // pixel on C addresses serialises: ~10 ms for 1M pixels)
   __shared__ unsigned int hist[64];
+  __shared__ unsigned int nvoid;
   if (threadIdx.x < 64) hist[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) nvoid = 0u;
   __syncthreads();
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
     const T* yp = y + p * ldy;
@@ -34,6 +40,14 @@ __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict_
       mx = fmaxf(mx, Elem<T>::ld(yp + c));
       const float tv = t[p * ldt + c];
       if (tv > tbest) { tbest = tv; label = c; }   // argmax, first maximum wins (torch.argmax)
+    }
+    if (!(tbest > 0.f)) {   // void pixel
+      for (int c = 0; c < C; ++c) {
+        keys[(long)c * npix + p] = -1.f;
+        vals[(long)c * npix + p] = (unsigned int)p;
+      }
+      atomicAdd(&nvoid, 1u);
+      continue;
     }
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += __expf(Elem<T>::ld(yp + c) - mx);
@@ -48,21 +62,23 @@ __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict_
   }
   __syncthreads();
   if (C <= 64 && threadIdx.x < C && hist[threadIdx.x]) atomicAdd(counts + threadIdx.x, hist[threadIdx.x]);
+  if (threadIdx.x == 0 && nvoid) atomicAdd(counts + C, nvoid);   // counts[C] = number of void pixels
 }
 
 // per class (blockIdx.y): g_i = jaccard(i) - jaccard(i-1) over the sorted order; loss_c += err_i * g_i; gerr[c][orig] = g_i
 __global__ __launch_bounds__(256) void lovasz_grad_kernel(const float* __restrict__ keys_sorted, const unsigned int* __restrict__ vals_sorted,
                                                           const unsigned int* __restrict__ cum, const unsigned int* __restrict__ counts,
-                                                          float* __restrict__ gerr, double* __restrict__ lossc, long npix) {
+                                                          float* __restrict__ gerr, double* __restrict__ lossc, long npix, int C) {
   __shared__ float sh[4];
   const int c = blockIdx.y;
+  const long nvalid = npix - (long)counts[C];
   const double gts = (double)counts[c];
   const float* ks = keys_sorted + (long)c * npix;
   const unsigned int* vs = vals_sorted + (long)c * npix;
   const unsigned int* cu = cum + (long)c * npix;
   float part = 0.f;
   if (gts > 0.) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvalid; i += (long)gridDim.x * 256) {
       const double ci = (double)cu[i];
       const double jac = 1.0 - (gts - ci) / (gts + (double)(i + 1) - ci);
       double prev = 0.0;
@@ -102,6 +118,7 @@ __global__ __launch_bounds__(256) void lovasz_backward_kernel(const T* __restric
       const float tv = t[p * ldt + c];
       if (tv > tbest) { tbest = tv; label = c; }
     }
+    if (!(tbest > 0.f)) continue;   // void pixel: not part of the loss
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += __expf(Elem<T>::ld(yp + c) - mx);
     const float inv = 1.f / se;
@@ -141,7 +158,7 @@ Layout layout(long npix, int C) {
   L.vals_out = off; off = al(off + n * 4);
   L.cum = off; off = al(off + n * 4);
   L.gerr = off; off = al(off + n * 4);
-  L.counts = off; off = al(off + (size_t)C * 4);
+  L.counts = off; off = al(off + (size_t)(C + 1) * 4);
   L.lossc = off; off = al(off + (size_t)C * 8);
   size_t t1 = 0, t2 = 0;
   (void)rocprim::radix_sort_pairs_desc(nullptr, t1, (const float*)nullptr, (float*)nullptr, (const unsigned int*)nullptr,
@@ -210,7 +227,7 @@ extern "C" int sdhip_lovasz_softmax(const void* logits, int ldy, const float* ta
       SDHIP_FAIL(SDHIP_ERR_LAUNCH, "lovasz_softmax: scan failed");
   }
   dim3 g2 = grid_for(npix); g2.y = C;
-  hipLaunchKernelGGL(lovasz_grad_kernel, g2, dim3(256), 0, s, keys_out, vals_out, cum, counts, gerr, lossc, npix);
+  hipLaunchKernelGGL(lovasz_grad_kernel, g2, dim3(256), 0, s, keys_out, vals_out, cum, counts, gerr, lossc, npix, C);
   if (dtype == SDHIP_F32)
     hipLaunchKernelGGL(lovasz_backward_kernel<float>, grid_stream(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, gerr, counts, lossc, (float*)grad, ldg, loss, npix, C, weight);
   else

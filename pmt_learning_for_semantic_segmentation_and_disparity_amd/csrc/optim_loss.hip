@@ -78,14 +78,16 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ y, int ld
   if (threadIdx.x == 0) atomicAdd(loss, (double)tot * (double)wnorm);
 }
 
-// loss += weight/n * sum |a - b| ; ga = weight/n * sign(a - b)
+// loss += weight/n * sum |a - b| ; ga = weight/n * sign(a - b).  mask_nonpositive: elements whose target is <= 0 count as
+// zero difference but stay in the mean (L1(pred*zeros, disp*zeros), zeros = disp > 0: losses/multiLosses.py:138-141)
 template <typename T>
 __global__ __launch_bounds__(256) void l1_kernel(const T* __restrict__ a, const float* __restrict__ b, T* __restrict__ ga,
-                                                 double* __restrict__ loss, long n, float wnorm) {
+                                                 double* __restrict__ loss, long n, float wnorm, int mask_nonpositive) {
   __shared__ float sh[4];
   float part = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float d = Elem<T>::ld(a + i) - b[i];
+    const float bi = b[i];
+    const float d = (mask_nonpositive && !(bi > 0.f)) ? 0.f : Elem<T>::ld(a + i) - bi;
     part += fabsf(d);
     if (ga) Elem<T>::st(ga + i, d > 0.f ? wnorm : (d < 0.f ? -wnorm : 0.f));
   }
@@ -138,14 +140,14 @@ extern "C" int sdhip_ce_loss(const void* logits, int ldy, const float* target, i
 }
 
 extern "C" int sdhip_l1_loss(const void* pred, const float* target, void* grad, double* loss, long n, float weight,
-                             int dtype, void* stream) {
+                             int mask_nonpositive, int dtype, void* stream) {
   SDHIP_CHECK_ARG(pred && target && loss && n > 0, "l1_loss: bad arguments");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "l1_loss: unknown dtype %d", dtype);
   const float wn = weight / (float)n;
   if (dtype == SDHIP_F32)
-    hipLaunchKernelGGL(l1_kernel<float>, grid_loss(n), dim3(256), 0, (hipStream_t)stream, (const float*)pred, target, (float*)grad, loss, n, wn);
+    hipLaunchKernelGGL(l1_kernel<float>, grid_loss(n), dim3(256), 0, (hipStream_t)stream, (const float*)pred, target, (float*)grad, loss, n, wn, mask_nonpositive);
   else
-    hipLaunchKernelGGL(l1_kernel<bf16_t>, grid_loss(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, target, (bf16_t*)grad, loss, n, wn);
+    hipLaunchKernelGGL(l1_kernel<bf16_t>, grid_loss(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, target, (bf16_t*)grad, loss, n, wn, mask_nonpositive);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }

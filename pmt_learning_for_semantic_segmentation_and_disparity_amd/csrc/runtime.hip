@@ -3,7 +3,7 @@
 // entry points are re-entrant from autograd's backward threads.
 #include "sdhip_common.h"
 
-#define SDHIP_ABI_VERSION 1
+#define SDHIP_ABI_VERSION 2
 
 static thread_local char g_err[512] = "";
 

@@ -434,6 +434,7 @@ class dsnet(nn.Module):
     """models/dsnet_t2.py:119-321 — the PyTorch port of the TF `baseline_SDnet_small_fixed` graph (BASELINE config 2):
     2-D 17x17 correlation, stride-2 transposed convs, log-softmax heads blended 0.9/0.1 and 0.8/0.2.
     forward(left, right) -> (seg_branch, disp_out, seg_branch2, disp_out2)."""
+    _match_channels = 289      # input channels of corrConv2d: the 17 x 17 displacements
 
     def __init__(self, CFG, labels=8, pretrained=False, backbone='densenet'):
         super().__init__()
@@ -441,7 +442,7 @@ class dsnet(nn.Module):
         for j in (1, 2, 3):
             setattr(self, 'conv2d_ba%d' % j, _img_conv(3))
         self.correlation_sampler = SpatialCorrelationSampler(1, (17, 17), 1, 0, dilation_patch=1)
-        self.corrConv2d = _c1x1(289, 128)
+        self.corrConv2d = _c1x1(self._match_channels, 128)
         self.conv1d_1 = _c1x1(2048, 64)
         self.Conv2DownUp1 = Conv2DownUp(64, 32, 3)
         self.Conv2DownUp2 = nn.Sequential(Conv2DownUp(32, 32, 3, lastLayer=False), ConvTranspose2dSame(32, labels, 3, 1, padding='same', init_he=False))
@@ -487,10 +488,7 @@ class dsnet(nn.Module):
         x1 = up(x, scale_factor=2, mode='nearest')
         seg1 = up(self.Conv2DownUp2[1](self.Conv2DownUp2[0](x1)), scale_factor=8, mode='nearest')
         seg1 = ops.log_softmax(up(seg1, size=size, mode='bilinear'))
-        y = self.correlation_sampler(a[5], b[5])
-        n, ph, pw, h, w = y.shape
-        y = y.reshape(n, ph * pw, h, w)
-        y = self.corrConv2d[0].run(ops.affine_act(y, ops._const_vec(1.0 / a[5].size(1), ph * pw, y.device), None), act=1)
+        y = self._match(a, b)
         y1 = up(self.Conv2DownUp3(x1), size=y.shape[2:], mode='bilinear')
         y = self.Conv2DownUp4(ops.concat([y1, y]))
         y2 = up(y, scale_factor=8)
@@ -522,3 +520,24 @@ class dsnet(nn.Module):
         d2 = self.Conv2DownUp10[1](self.Conv2DownUp10[0](self.conv1d_8[0].run(ops.concat([y, xl3]), act=1)))
         d2 = up(d2, size=size, mode='bilinear')
         return seg1, disp, seg2, ops.axpby(0.8, d2, 0.2, disp)
+
+    def _match(self, a, b):
+        """Left/right matching features at 1/8 resolution: 2-D correlation of the tap-2 pyramids / C, then 1x1 + ReLU
+        (models/dsnet_t2.py:221-224)."""
+        y = self.correlation_sampler(a[5], b[5])
+        n, ph, pw, h, w = y.shape
+        y = y.reshape(n, ph * pw, h, w)
+        return self.corrConv2d[0].run(ops.affine_act(y, ops._const_vec(1.0 / a[5].size(1), ph * pw, y.device), None), act=1)
+
+
+class dsnetnoCorr(dsnet):
+    """models/dsnet_t2.py:620-823 — the PyTorch port of the TF `baseline_SDnet_small` graph (BASELINE config 1): `dsnet`
+    with the correlation replaced by a plain concatenation of the two towers' tap-2 maps (`:697-700`; the sampler is still
+    constructed, `:630-634`, and has no parameters).  forward(left, right) -> (seg_branch, disp_out, seg_branch2, disp_out2)."""
+    _match_channels = 512
+
+    def __init__(self, CFG, labels=8, pretrained=False):
+        super().__init__(CFG, labels=labels, pretrained=pretrained)
+
+    def _match(self, a, b):
+        return self.corrConv2d[0].run(ops.concat([a[2], b[2]]), act=1)

@@ -987,7 +987,7 @@ class _TrainLossFn(torch.autograd.Function):
     three network outputs are produced in the same pass."""
 
     @staticmethod
-    def forward(ctx, seg1, disp, seg2, seg_t, disp_t, use_lovasz):
+    def forward(ctx, seg1, disp, seg2, seg_t, disp_t, use_lovasz, mask_invalid_disp=False):
         _require_gpu(seg1, disp, seg2, seg_t, disp_t)
         B, C, H, W = seg1.shape
         npix = B * H * W
@@ -1006,7 +1006,7 @@ class _TrainLossFn(torch.autograd.Function):
         if not disp_t.is_contiguous():
             raise _lib.SdhipError("disparity target must be a dense (B,1,H,W) tensor")
         gd = torch.empty_like(dv)
-        call("sdhip_l1_loss", ptr(dv), ptr(disp_t), ptr(gd), ptr(loss), npix, 1.0, dt, stream_ptr())
+        call("sdhip_l1_loss", ptr(dv), ptr(disp_t), ptr(gd), ptr(loss), npix, 1.0, int(mask_invalid_disp), dt, stream_ptr())
         if use_lovasz:   # added onto the CE gradient of seg2 in place
             s2, ld2 = nhwc_view(seg2)
             nbytes = _lib.lovasz_workspace_bytes(npix, C)
@@ -1024,12 +1024,14 @@ class _TrainLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g1, gd, g2 = ctx.saved_tensors
-        return g1, gd, g2, None, None, None   # d(total)/d(total) is 1 in the training step
+        return g1, gd, g2, None, None, None, None   # d(total)/d(total) is 1 in the training step
 
 
-def train_loss(seg1, disp, seg2, seg_target, disp_target, use_lovasz=True):
-    """seg_target: one-hot f32 (B,C,H,W); disp_target: f32 (B,1,H,W)."""
-    return _TrainLossFn.apply(seg1, disp, seg2, seg_target, disp_target, use_lovasz)
+def train_loss(seg1, disp, seg2, seg_target, disp_target, use_lovasz=True, mask_invalid_disp=False):
+    """seg_target: one-hot f32 (B,C,H,W) — an all-zero row marks a void pixel (cityscapes: the 20th channel dropped,
+    losses/multiLosses.py:19-21): zero cross-entropy term, removed from the Lovasz term; disp_target: f32 (B,1,H,W);
+    mask_invalid_disp: disparities <= 0 are invalid (the cityscapes / kitti rule, losses/multiLosses.py:134-141)."""
+    return _TrainLossFn.apply(seg1, disp, seg2, seg_target, disp_target, use_lovasz, mask_invalid_disp)
 
 
 # ============================================================================ dropout / global average pool
@@ -1331,7 +1333,7 @@ class _MeanL1Fn(torch.autograd.Function):
         for p in preds:
             pv = p.contiguous()
             g = torch.empty_like(pv)
-            call("sdhip_l1_loss", ptr(pv), ptr(t), ptr(g), ptr(loss), pv.numel(), 1.0 / len(preds), dtype_code(pv), stream_ptr())
+            call("sdhip_l1_loss", ptr(pv), ptr(t), ptr(g), ptr(loss), pv.numel(), 1.0 / len(preds), 0, dtype_code(pv), stream_ptr())
             grads.append(g)
         ctx.save_for_backward(*grads)
         return loss.float()

@@ -46,6 +46,11 @@ const char* sdhip_last_error(void);
  * the library is loaded (a set switch is announced on stderr) and never per launch; a test or tool that changes the
  * environment for an A/B run inside one process calls this to re-read them.  No reference counterpart. */
 void sdhip_diag_reload(void);
+/* End a stream capture that failed half way (an uncapturable call invalidated it and the caller left its capture block
+ * by an exception): hipStreamEndCapture on `stream`, the partial graph destroyed, the sticky error cleared.  Returns 1 if a
+ * capture was still open, 0 if none was, < 0 if the stream cannot be brought back.  Host-side recovery for the training
+ * step's hipGraph (the reference has no graph capture; its counterpart is simply running the step eagerly). */
+int sdhip_abort_capture(void* stream);
 
 /* ---------------------------------------------------------------------------
  * Spatial correlation sampler  (third-party op `SpatialCorrelationSampler`,

@@ -101,6 +101,16 @@ def packed_elems(M, K, T, dt):
 
 
 _lib.sdhip_diag_reload.restype = None
+_lib.sdhip_abort_capture.argtypes = [_p]
+_lib.sdhip_abort_capture.restype = _i
+
+
+def abort_capture(stream):
+    """End a broken hipGraph capture on `stream` (a torch.cuda.Stream); returns 1 if one was open (see include/sdhip.h)."""
+    rc = _lib.sdhip_abort_capture(ctypes.c_void_p(stream.cuda_stream))
+    if rc < 0:
+        raise SdhipError("sdhip_abort_capture failed: %s" % _lib.sdhip_last_error().decode())
+    return rc
 
 
 def reload_diag():

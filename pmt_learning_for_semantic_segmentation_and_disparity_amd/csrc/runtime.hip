@@ -50,3 +50,28 @@ const SdhipDiag& sdhip_diag() {
 }
 __attribute__((constructor)) static void diag_at_load() { diag_fill(); }
 extern "C" void sdhip_diag_reload(void) { diag_fill(); }
+
+// ---- recovery from a stream capture that failed half way (train.TrainStep) -------------------------------------------
+// An illegal call during hipStreamBeginCapture..EndCapture invalidates the capture, but the stream stays in capture mode
+// until hipStreamEndCapture has been called on it; a caller that raised out of its capture block (PyTorch's graph context
+// does, and then skips its own clean-up) leaves the process unable to launch anything.  This ends the capture, drops the
+// partial graph and clears the sticky error.  Returns 1 if a capture was still open, 0 if not, < 0 on failure.
+extern "C" int sdhip_abort_capture(void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  hipError_t e = hipStreamIsCapturing(s, &st);
+  (void)hipGetLastError();
+  int was_open = 0;
+  if (e != hipSuccess || st != hipStreamCaptureStatusNone) {
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(s, &g);        // returns hipErrorStreamCaptureInvalidated for a broken capture: expected
+    (void)hipGetLastError();
+    if (g) (void)hipGraphDestroy(g);
+    was_open = 1;
+  }
+  st = hipStreamCaptureStatusNone;
+  e = hipStreamIsCapturing(s, &st);
+  (void)hipGetLastError();
+  if (e != hipSuccess || st != hipStreamCaptureStatusNone) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "abort_capture: the stream is still capturing");
+  return was_open;
+}

@@ -46,6 +46,11 @@ class TrainStep:
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.beta_pow = torch.ones(2, dtype=torch.float32, device=self.flat_p.device)
         self.use_graph = use_graph
+        if use_graph and world_size > 1 and _backend_of(process_group) != "nccl":
+            # host-staged collectives (gloo: rehearsals and tests on fewer GPUs than ranks) cannot be part of a hipGraph
+            import sys
+            sys.stderr.write("[TrainStep] process group backend %r cannot be captured: running WITHOUT a graph\n" % _backend_of(process_group))
+            self.use_graph = False
         # Weight gradients on a second captured stream: on one GPU every kernel fills the chip and the overlap buys nothing
         # (measured 31.8 ms without vs 32.5 ms with), but under data parallelism the main stream sits in ~400 latency-bound
         # sync-BN all-reduces per step — the weight gradients then run inside those waits.
@@ -127,29 +132,63 @@ class TrainStep:
     def capture(self, left, right, seg, disp, warmup=2):
         """Warm up eagerly on a side stream, then record forward+backward(+all-reduce)+Adam as one hipGraph."""
         self.static = [t.clone() for t in (left, right, seg, disp)]
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        # warm-up and capture share ONE side stream: autograd's AccumulateGrad nodes remember the stream they were created
+        # on (the first forward), and a different capture stream would make every parameter gradient cross streams
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
             for _ in range(warmup):
                 self._eager(*self.static)
-        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        torch.cuda.empty_cache()
+        graph = torch.cuda.CUDAGraph()
         # data parallel: the RCCL watchdog thread polls events while we capture; thread-local capture errors keep its
         # (legal) calls from invalidating the capture of this thread
         mode = "thread_local" if self.world_size > 1 else "global"
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
-            self.loss = self._eager(*self.static)
-            if self._capture_fault is not None:
-                self._capture_fault()
+        # The capture is driven by hand instead of through `torch.cuda.graph`: that context manager re-raises out of its
+        # __exit__ when the capture was invalidated and then neither restores the current stream nor ends the capture,
+        # which leaves the whole process unable to launch (observed on ROCm 7.2: every later call fails with
+        # hipErrorStreamCaptureInvalidated).  Here a failure ends the capture explicitly (sdhip_abort_capture).
+        with torch.cuda.stream(cap):
+            graph.capture_begin(capture_error_mode=mode)
+            try:
+                self.loss = self._eager(*self.static)
+                if self._capture_fault is not None:
+                    self._capture_fault()
+                graph.capture_end()
+            except BaseException:
+                self._close_broken_capture(graph, cap)
+                raise
+        torch.cuda.current_stream().wait_stream(cap)
+        self.graph = graph
         return self
+
+    def _close_broken_capture(self, graph, cap):
+        """Best-effort return to a launchable process after an exception inside the capture."""
+        try:
+            graph.capture_end()                  # ends the allocator's pool redirection when the capture itself is intact
+        except BaseException:
+            pass
+        streams = [cap] + ([self.ctx.side] if self.ctx.side is not None else [])
+        for st in streams:
+            try:
+                _lib.abort_capture(st)
+            except _lib.SdhipError as e:
+                import sys
+                sys.stderr.write("[TrainStep] %s\n" % e)
+        try:
+            torch._C._cuda_endAllocateToPool(self.flat_p.device.index or 0, graph.pool())
+        except BaseException:
+            pass
+        del graph
 
     def _abandon_capture(self):
         """A capture that raised recorded launches but executed none: device state (parameters, moments, running
         statistics, dropout seed) is that of the last eager warm-up step.  Only host-side bookkeeping of the half-recorded
         step has to be reset before eager steps continue."""
         self.graph, self.use_graph, self.loss = None, False, None
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()               # raises if the process could not be brought back: nothing can run then
         self.ctx.unpacks = []
         self.ctx.keep.clear()
         ops.invalidate_packed_weights()
@@ -171,6 +210,14 @@ class TrainStep:
         self.graph.replay()
         self.steps_done += 1
         return self.loss
+
+
+def _backend_of(pg):
+    import torch.distributed as dist
+    try:
+        return dist.get_backend(pg)
+    except Exception:
+        return None
 
 
 def _rank_of(pg):

@@ -240,8 +240,9 @@ def test_hip_large_config_properties(B, H, W, aspp):
     loss = ops.train_loss(outs[0], outs[1], outs[2], seg, disp, True, True)
     loss.backward()
     assert torch.isfinite(loss).all()
+    bad = [k for k, p in m.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
     g = [p.grad for p in m.parameters() if p.grad is not None]
-    assert len(g) > 1000 and all(torch.isfinite(t).all() for t in g)
+    assert len(g) > 500 and not bad, (len(g), bad[:8])
     sm = StepMetrics(19, device="cuda")
     sm.update(outs[2].detach(), seg, outs[1].detach(), disp)
     res = sm.compute()
@@ -361,5 +362,7 @@ def test_bf16_trains_like_f32():
         del ts, m
     f, h = np.array(traj[torch.float32]), np.array(traj[torch.bfloat16])
     assert np.isfinite(f).all() and np.isfinite(h).all()
-    assert f[-10:].mean() < 0.7 * f[:3].mean() and h[-10:].mean() < 0.7 * h[:3].mean(), (f[:3], f[-10:], h[:3], h[-10:])
-    assert abs(h[-10:].mean() - f[-10:].mean()) <= 0.1 * f[-10:].mean(), (f[-10:].mean(), h[-10:].mean())
+    # (random labels: what can be learnt in 50 steps is the class prior and the disparity scale — about 20 % of the loss)
+    assert f[-10:].mean() < 0.9 * f[:3].mean() and h[-10:].mean() < 0.9 * h[:3].mean(), (f[:3], f[-10:], h[:3], h[-10:])
+    assert abs(h[-10:].mean() - f[-10:].mean()) <= 0.05 * f[-10:].mean(), (f[-10:].mean(), h[-10:].mean())
+    assert np.abs(h - f).max() <= 0.1 * f.max(), (f, h)

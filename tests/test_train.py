@@ -152,7 +152,7 @@ def test_dropout_seed_advances_every_step(graph):
         seeds.append(int(seed.item()))
     ops.set_step_context(None)
     assert [b - a for a, b in zip(seeds, seeds[1:])] == [1, 1, 1, 1], seeds
-    assert ts.steps_done == 5
+    assert ts.steps_done == (7 if graph else 5)      # the first graph call runs 2 eager warm-up steps before its replay
     assert len({round(l, 6) for l in losses[2:]}) == 3, losses     # same weights, same batch, different masks
 
 

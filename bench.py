@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--model", default="minidsnetExt", choices=["minidsnetExt", "psmnet", "dsnet"],
+    ap.add_argument("--model", default="minidsnetExt", choices=["minidsnetExt", "psmnet", "dsnet", "dsnetnoCorr"],
                     help="psmnet = BASELINE config 3 (PSMNet(192), build-defined loss: mean L1 of the three predictions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -41,7 +41,10 @@ def parse():
                     help="nccl = RCCL over xGMI (production).  gloo: rehearsal of the N-rank path on a box with fewer GPUs than ranks "
                          "(ranks share devices, collectives go through the host; the number it prints is not a result)")
     ap.add_argument("--rank-probe", action="store_true", help="each rank prints its launch environment and exits (CPU test of the launcher)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU results (dsnet = config 2 as literally named, PSMNet(192) B=8 = config 3)")
+    ap.add_argument("--secondary-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-warmup", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=16)
     return ap.parse_args()
 
@@ -52,6 +55,8 @@ def build_model(dtype, name="minidsnetExt"):
     torch.manual_seed(0)
     if name == "dsnet":
         return N.dsnet(CFG(), labels=2, pretrained=False).cuda().train()
+    if name == "dsnetnoCorr":
+        return N.dsnetnoCorr(CFG(), labels=2, pretrained=False).cuda().train()
     if name == "psmnet":
         from pmt_learning_for_semantic_segmentation_and_disparity_amd.psmnet import PSMNet
         return PSMNet(192).cuda().train()
@@ -88,19 +93,113 @@ def kernel_roofline(dtype, B, H, W):
     ach = flops / (ms * 1e-3) / 1e12
     # HBM bytes per launch of this kernel from the PMC passes committed under profiles/ (FETCH_SIZE doubled as the gfx950
     # note of MI355X_MICROARCH.md prescribes, + WRITE_SIZE; tools/roofline_profile.sh); null when no profile is committed
-    traffic = None
-    tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_roofline_traffic.json")
-    if dtype == torch.bfloat16 and (B, H, W) == (8, 256, 512) and os.path.exists(tj):
-        try:
-            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, src, busy = None, None, None
+    for name in ("r02_roofline_traffic.json", "r01_roofline_traffic.json"):
+        tj = os.path.join(ROOT, "profiles", name)
+        if dtype == torch.bfloat16 and (B, H, W) == (8, 256, 512) and os.path.exists(tj):
+            try:
+                j = json.load(open(tj))
+                traffic, src, busy = j.get("hbm_bytes_per_launch"), "profiles/" + name, j.get("mfma_busy_frac")
+                break
+            except Exception:
+                pass
     return {"bound": "mfma", "kernel": "conv_fast_kernel<bf16, 8x32 tile, 64 out-ch block, LDS-DMA> 5x5 64->64 @%dx%dx%d" % (B, H, W),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "traffic_source": (src + " (PMC passes of `bench.py --roofline-only`, tools/roofline_profile.sh; not measured in this run)") if src else None,
+            "mfma_busy_frac": busy, "algorithmic_bytes": 2 * B * H * W * C * (2 if dtype == torch.bfloat16 else 4) + C * C * 25 * 2,
             "ms_per_launch": round(ms, 4)}
 
 
-def cpu_baseline(B, H, W, steps, threads=16):
+def hbm_kernel_roofline(dtype, B, H, W):
+    """The largest HBM-bound kernel family of the step, timed alone with HIP events on its own stream: the second pass of
+    the BatchNorm backward (`bn_bwd_apply_fin`) on a (B,64,H,W) map — reads the incoming gradient and the raw convolution
+    output, writes the gradient of the raw output: 3 tensors of B*H*W*64 elements (+ per-channel vectors)."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops, _lib
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd._lib import call, ptr
+    C = 64
+    npix = B * H * W
+    g = torch.randn(B, H, W, C, device="cuda").to(dtype)
+    x = torch.randn(B, H, W, C, device="cuda").to(dtype)
+    gx = torch.empty_like(x)
+    vec = lambda v: torch.full((1, C), v, dtype=torch.float32, device="cuda")
+    scale, shift, mean, invstd, gamma, beta = vec(1.0), vec(0.1), vec(0.0), vec(1.0), vec(1.0)[0].clone(), vec(0.0)[0].clone()
+    dsc = torch.zeros(ops.NREP, 1, C, device="cuda"); dsh = torch.zeros(ops.NREP, 1, C, device="cuda")
+    dgamma = torch.zeros(C, device="cuda"); dbeta = torch.zeros(C, device="cuda")
+    dt = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+    s = torch.cuda.Stream()
+    n = 20
+    with torch.cuda.stream(s):
+        def launch():
+            call("sdhip_bn_bwd_apply_fin", ptr(g), C, ptr(x), C, ptr(gx), C, ptr(scale), ptr(shift), ptr(dsc), ptr(dsh), ops.NREP,
+                 ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), 0, npix, C, 1, float(npix), 1, dt,
+                 ctypes_stream(s))
+        for _ in range(3):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(n):
+            launch()
+        e1.record(s)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    nbytes = 3 * npix * C * (2 if dtype == torch.bfloat16 else 4)
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "bn_bwd_apply_fin (BatchNorm backward, second pass) on (%d,64,%d,%d)" % (B, H, W),
+            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+            "algorithmic_bytes": nbytes, "ms_per_launch": round(ms, 4), "traffic": None}
+
+
+def ctypes_stream(s):
+    import ctypes
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+# algorithmic work per stereo pair of one training step at 256x512 (SURVEY 8d: forward MACs x 2 FLOP x 3 for fwd+dgrad+wgrad;
+# conv activation bytes, each conv reading its input and writing its output once, x 3); scaled by H*W
+WORK = {"minidsnetExt": (643.0e9, 2.3e9), "dsnet": (3 * 2 * 195.4e9, 2.3e9 * 195.4 / 107.17), "psmnet": (1108.2e9, 3 * 0.73e9 + 3 * 0.4e9)}
+
+
+def step_roofline(model, B, H, W, ms, dtype):
+    fl, by = WORK[model]
+    k = (H * W) / (256.0 * 512.0)
+    fl, by = fl * k * B, by * k * B * (1.0 if dtype == "bf16" else 2.0)
+    t = ms * 1e-3
+    mf_peak = 2500.0 if dtype == "bf16" else 157.3
+    return {"flops_per_step": fl, "bytes_per_step": by, "achieved_tflops": round(fl / t / 1e12, 1), "mfma_peak_tflops": mf_peak,
+            "mfma_frac": round(fl / t / 1e12 / mf_peak, 4), "achieved_gbs": round(by / t / 1e9, 1), "hbm_peak_gbs": 8000.0,
+            "hbm_frac": round(by / t / 1e9 / 8000.0, 4),
+            "ideal_ms": round((fl / (mf_peak * 1e12) + by / 8.0e12) * 1e3, 2),
+            "note": "whole training step (fwd + loss + bwd + Adam): algorithmic FLOPs and conv-activation bytes of SURVEY 8d vs both roofs"}
+
+
+def time_model(name, dtype, B, H, W, steps, warmup, world=1, pg=None, use_graph=True, seed=1234):
+    """Build `name`, run `warmup` untimed + `steps` timed training steps on a resident synthetic batch; (ms/step, loss, graph?)."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops as _ops
+    model = build_model(dtype, name)
+    loss_fn = None
+    if name == "psmnet":
+        loss_fn = lambda outs, seg, disp: _ops.mean_l1_loss(outs, disp[:, 0])
+    elif name in ("dsnet", "dsnetnoCorr"):
+        loss_fn = lambda outs, seg, disp: _ops.train_loss(outs[0], outs[1], outs[2], seg, disp, True)
+    step = TrainStep(model, dtype=dtype, use_graph=use_graph, world_size=world, process_group=pg, loss_fn=loss_fn)
+    batch = synthetic_batch(B, H, W, seed=seed)
+    for _ in range(warmup):
+        loss = step(*batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(*batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = (dt / steps * 1e3, float(loss.item()), step.use_graph)
+    _ops.set_step_context(None)
+    del step, model, batch
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(B, H, W, steps, threads=16, warmup=3):
     """The CPU oracle (a port of the reference graph to plain torch.nn) on the host cores: fwd + loss + bwd."""
     import torch.nn.functional as F
     from oracle import ref_models as R
@@ -116,8 +215,8 @@ def cpu_baseline(B, H, W, steps, threads=16):
     m = R.minidsnetExt(R.CFG(), labels=2, patch_type='1dcorr').train()
     left, right, seg, disp = synthetic_batch(B, H, W, device="cpu")
     ts = []
-    for i in range(steps + 1):
-        sys.stderr.write("[bench] cpu_baseline step %d/%d on %d threads\n" % (i, steps, cores)); sys.stderr.flush()
+    for i in range(steps + warmup):
+        sys.stderr.write("[bench] cpu_baseline step %d/%d on %d threads\n" % (i, steps + warmup, cores)); sys.stderr.flush()
         t0 = time.time()
         o = m(left, right)
         ce = lambda y: torch.mean(torch.sum(-seg * F.log_softmax(y, 1), 1))
@@ -125,9 +224,10 @@ def cpu_baseline(B, H, W, steps, threads=16):
         m.zero_grad(set_to_none=True)
         loss.backward()
         ts.append(time.time() - t0)
-    t = sum(ts[1:]) / max(1, len(ts) - 1)   # first step is warm-up
+    t = sum(ts[warmup:]) / max(1, len(ts) - warmup)
     return {"value": round(B / t, 4), "unit": "stereo-pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of B=%d %dx%d fp32 fwd+loss+bwd after 1 warm-up (oracle/ref_models.py)" % (steps, B, W, H)}
+            "sample": "%d steps of B=%d %dx%d fp32 fwd+loss(CE+CE+Lovasz+L1)+bwd after %d warm-up steps (oracle/ref_models.py, the "
+                      "CPU restatement pinned to the reference by tests/golden)" % (steps, B, W, H, warmup)}
 
 
 def spawn_ranks(a):
@@ -191,9 +291,11 @@ def main():
         return
     model = build_model(dtype, a.model)
     loss_fn = None
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops as _ops
     if a.model == "psmnet":
-        from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops as _ops
         loss_fn = lambda outs, seg, disp: _ops.mean_l1_loss(outs, disp[:, 0])
+    elif a.model in ("dsnet", "dsnetnoCorr"):     # log-softmax heads: the same CE + Lovasz + L1 composition applies to them
+        loss_fn = lambda outs, seg, disp: _ops.train_loss(outs[0], outs[1], outs[2], seg, disp, True)
     step = TrainStep(model, dtype=dtype, use_graph=not a.no_graph, world_size=world, process_group=pg, loss_fn=loss_fn)
     batch = synthetic_batch(a.batch, a.height, a.width, seed=1234 + rank)
     for _ in range(a.warmup):
@@ -232,10 +334,26 @@ def main():
                           "backend": ("rccl" if a.backend == "nccl" else "gloo (rehearsal, not a result)") if world > 1 else None},
                "loss": round(lossv, 5)}
         sys.stderr.write("[bench] timed region done: %.3f ms/step\n" % (dt / a.steps * 1e3)); sys.stderr.flush()
+        out["step_roofline"] = step_roofline(a.model if a.model != "dsnetnoCorr" else "dsnet", a.batch * world, a.height, a.width,
+                                             dt / a.steps * 1e3, a.dtype)
         if not a.no_roofline:
+            del step, model
+            _ops.set_step_context(None)
+            torch.cuda.empty_cache()
             out["roofline"] = kernel_roofline(dtype, a.batch, a.height, a.width)
+            out["roofline_hbm"] = hbm_kernel_roofline(dtype, a.batch, a.height, a.width)
+        if world == 1 and not a.no_secondary and a.model == "minidsnetExt" and not a.no_graph:
+            sec = []
+            for name, sb, label in (("dsnet", a.batch, "dsnet = PyTorch port of baseline_SDnet_small_fixed (BASELINE config 2 as literally named)"),
+                                    ("psmnet", 8, "PSMNet(192) stacked hourglass, loss mean L1 x3 (BASELINE config 3, SURVEY 8d batch 8)")):
+                sys.stderr.write("[bench] secondary: %s B=%d\n" % (name, sb)); sys.stderr.flush()
+                ms, lv, gr = time_model(name, dtype, sb, a.height, a.width, a.secondary_steps, 1)
+                sec.append({"workload": "%s, %dx%d, batch %d, %s" % (label, a.width, a.height, sb, "hipGraph" if gr else "eager"),
+                            "value": round(sb / ms * 1e3, 2), "unit": "stereo-pairs/s", "ms_per_step": round(ms, 3), "steps": a.secondary_steps,
+                            "loss": round(lv, 5), "step_roofline": step_roofline(name, sb, a.height, a.width, ms, a.dtype)})
+            out["secondary"] = sec
         if world == 1 and not a.no_cpu_baseline and a.model == "minidsnetExt":
-            out["cpu_baseline"] = cpu_baseline(2, a.height, a.width, a.cpu_steps, a.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(2, a.height, a.width, a.cpu_steps, a.cpu_threads, a.cpu_warmup)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()     # rank 0 may still be in its single-rank roofline measurement: leave together

@@ -1044,7 +1044,10 @@ _RNG_BASE, _RNG_RANK_STRIDE = 0x5DEECE66D, 0x9E3779B97F4A7C15 >> 1
 def rng_seed_tensor(device):
     """Device-resident dropout seed.  train.TrainStep advances it once per step with a device-side add (captured into the
     step's hipGraph, so replays draw new masks); forward and backward of one step read the same value."""
-    if _rng["seed"] is None or _rng["seed"].device != torch.device(device):
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:       # "cuda" and "cuda:0" must name the same tensor: a captured step
+        device = torch.device("cuda", torch.cuda.current_device())   # keeps adding to the one it was recorded with
+    if _rng["seed"] is None or _rng["seed"].device != device:
         _rng["seed"] = torch.full((1,), _RNG_BASE, dtype=torch.int64, device=device)
     return _rng["seed"]
 

@@ -182,6 +182,20 @@ class TrainStep:
         except BaseException:
             pass
         del graph
+        # capture_begin put torch's default CUDA generator into capture mode and only a completed capture_end takes it
+        # out again ("Offset increment outside graph capture" on the next torch.randn(device='cuda')): a trivial
+        # capture that does complete resets it
+        try:
+            torch.cuda.synchronize()
+            g2, scratch = torch.cuda.CUDAGraph(), torch.zeros(1, device=self.flat_p.device)
+            with torch.cuda.stream(cap):
+                g2.capture_begin()
+                scratch.add_(1)
+                g2.capture_end()
+            del g2
+        except BaseException as e:
+            import sys
+            sys.stderr.write("[TrainStep] could not reset the capture state of torch's CUDA generator: %s\n" % str(e).splitlines()[0])
 
     def _abandon_capture(self):
         """A capture that raised recorded launches but executed none: device state (parameters, moments, running

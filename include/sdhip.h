@@ -135,6 +135,15 @@ int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* d
                        int kh, int kw, int stride, int dil, int pad_t, int pad_l,
                        int D, int Do, int kd, int sd, int pad_d,
                        int in_relu, int groups, int prezeroed, int dtype, void* stream);
+
+/* 1x1 convolution (+ bias, + activation) over the channel concatenation [x0 | x1] without materialising it; segment i is
+ * read at pixel (h >> us_i, w >> us_i) of a (B, c_i, H >> us_i, W >> us_i) map, i.e. nearest-neighbour upsampled by
+ * 2^us_i on the fly.  Replaces `conv1d_2(torch.cat((F.interpolate(y, scale_factor=8), xleft2), 1))` and the other
+ * concat -> 1x1 -> ReLU sites of models/dsnet_t2.py:1206-1216,1262-1291,927-933 (the x8 map of :1211 is never written).
+ * wpacked: sdhip_conv_pack_weights of the (Cout, c0 + c1, 1, 1) weight; c0 a multiple of 8; bf16 only. */
+int sdhip_conv1x1_cat_fwd(const void* x0, int ld0, int c0, int us0, const void* x1, int ld1, int c1, int us1,
+                          const void* wpacked, void* y, int ldy, const float* bias,
+                          int B, int H, int W, int Cout, int act, int dtype, void* stream);
 /* Pack many weights in one launch: desc = ndesc rows of 8 int64 {src ptr, dst ptr, M, K, T, stride_m, stride_k, flip}
  * in device memory (same layout rules as sdhip_conv_pack_weights). */
 int sdhip_conv_pack_batch(const long* desc, int ndesc, int dtype, void* stream);

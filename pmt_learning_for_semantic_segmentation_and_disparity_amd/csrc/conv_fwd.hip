@@ -16,6 +16,7 @@
 // sum / sum-of-squares for the BatchNorm that follows).
 #include "conv_common.h"
 #include "conv_fast.h"
+#include "conv_gemm.h"
 #include "conv_thin.h"
 
 namespace {
@@ -486,6 +487,19 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
     SDHIP_LAUNCH_CHECK();
     return SDHIP_OK;
   }
+  // ---- 1x1 as a streaming GEMM (conv_gemm.h): bf16, plain stride-1 1x1 over whole images ----
+  if (dtype == SDHIP_BF16 && kh == 1 && kw == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && D == 1 && Do == 1 &&
+      Ho == H && Wo == W && !accumulate && !dg.conv_generic && !dg.conv_no_gemm) {
+    GemmArgs g;
+    g.seg[0] = GemmSeg{x, ldx, Cin, 0};
+    g.seg[1] = GemmSeg{nullptr, 0, 0, 0};
+    g.nseg = 1;
+    g.wp = wpacked; g.y = y; g.bias = bias; g.in_scale = in_scale; g.in_shift = in_shift; g.stats = stats;
+    g.ldy = ldy; g.Cout = Cout; g.Mpad = a.Mpad; g.K = Cin; g.in_relu = in_relu; g.act = act;
+    g.M = (long)B * H * W; g.H = H; g.W = W; g.ppg = g.M / groups;
+    g.stats_ld = a.stats_ld; g.nrep = a.nrep; g.rep_stride = a.rep_stride;
+    if (gemm1x1_ok(g, (in_scale || stats) ? groups : 1)) return launch_gemm_any(g, s);
+  }
   // ---- fast path (conv_fast.h): 16-byte-aligned pixels on both sides, halo-tile mode ----
   if (!per_tap_any && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && a.vec_out &&
       (long)H * W * ldx < (1L << 31) && !dg.conv_generic) {
@@ -554,4 +568,24 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
     return big ? launch_bn<float, 8, 32>(a, bn, lds, s) : launch_bn<float, 4, 16>(a, bn, lds, s);
   }
   SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd: no tile configuration fits");
+}
+
+// 1x1 convolution over the channel concatenation of up to two tensors, either of which may be a nearest-neighbour
+// upsampled map (see include/sdhip.h).  bf16 only: the f32 parity path materialises the concatenation.
+extern "C" int sdhip_conv1x1_cat_fwd(const void* x0, int ld0, int c0, int us0, const void* x1, int ld1, int c1, int us1,
+                                     const void* wpacked, void* y, int ldy, const float* bias,
+                                     int B, int H, int W, int Cout, int act, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(x0 && wpacked && y && c0 > 0 && B > 0 && H > 0 && W > 0 && Cout > 0, "conv1x1_cat_fwd: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_BF16, "conv1x1_cat_fwd: bf16 only");
+  SDHIP_CHECK_ARG((x1 == nullptr) == (c1 == 0) && us0 >= 0 && us1 >= 0 && us0 < 8 && us1 < 8, "conv1x1_cat_fwd: bad second segment");
+  GemmArgs g;
+  g.seg[0] = GemmSeg{x0, ld0, c0, us0};
+  g.seg[1] = GemmSeg{x1, ld1, c1, us1};
+  g.nseg = x1 ? 2 : 1;
+  g.wp = wpacked; g.y = y; g.bias = bias; g.in_scale = nullptr; g.in_shift = nullptr; g.stats = nullptr;
+  g.ldy = ldy; g.Cout = Cout; g.Mpad = (Cout + 15) & ~15; g.K = c0 + c1; g.in_relu = 0; g.act = act;
+  g.M = (long)B * H * W; g.H = H; g.W = W; g.ppg = g.M;
+  g.stats_ld = Cout; g.nrep = 1; g.rep_stride = 0;
+  if (!gemm1x1_ok(g, 1)) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv1x1_cat_fwd: operands not 16-byte aligned / grid not divisible by the upsampling factor");
+  return launch_gemm_any(g, (hipStream_t)stream);
 }

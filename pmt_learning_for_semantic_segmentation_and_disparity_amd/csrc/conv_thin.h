@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void conv_thin_fwd_kernel(const ThinArgs p) {
         Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(xb + ((long)ih * p.W + iw) * p.ldx), f);
         const float* wt = wsm[khi * p.kw + kwi];
 #pragma unroll
-        for (int c = 0; c < (V < 8 ? V : 8); ++c) acc = fmaf(f[c], wt[c], acc);
+        for (int c = 0; c < (V < 8 ? V : 8); ++c) acc = fmaf(c < p.Cin ? f[c] : 0.f, wt[c], acc);   // pad channels of the pixel stride are not data (may be NaN)
       }
     }
     if (p.bias) acc += p.bias[0];

@@ -687,6 +687,24 @@ class _BNActFn(torch.autograd.Function):
         return gx, (dS if train else None), dgamma, dbeta, None, None, None
 
 
+def conv1x1_cat_forward(segs, weight, bias, act):
+    """act(conv1x1(cat([upsample_nearest(x_i, 2^us_i)], dim=1)) + bias) without building the concatenation or the
+    upsampled maps (sdhip_conv1x1_cat_fwd).  segs: [(tensor (B, c_i, H >> us_i, W >> us_i), us_i)], at most two; bf16."""
+    (x0, us0) = segs[0]
+    x1, us1 = segs[1] if len(segs) > 1 else (None, 0)
+    B, c0 = x0.shape[0], x0.shape[1]
+    H, W = x0.shape[2] << us0, x0.shape[3] << us0
+    v0, ld0 = aligned_view(x0)
+    v1, ld1 = aligned_view(x1) if x1 is not None else (None, 0)
+    c1 = x1.shape[1] if x1 is not None else 0
+    Cout = weight.shape[0]
+    wp = packed_weight(weight, 'conv', 'fwd', x0.dtype)
+    y, ldy = alloc_nhwc(B, Cout, H, W, x0.dtype, x0.device)
+    call("sdhip_conv1x1_cat_fwd", ptr(v0), ld0, c0, us0, ptr(v1), ld1, c1, us1, ptr(wp), ptr(y), ldy,
+         ptr(bias.detach()) if bias is not None else None, B, H, W, Cout, act, dtype_code(x0), stream_ptr())
+    return y
+
+
 def conv_same_geometry(H, W, k, stride, dil):
     """TF-'same' padding of conv2dSame (models/torch_model.py:276-281): output ceil(size/stride), extra pad bottom/right."""
     def one(size):

@@ -35,3 +35,23 @@ for lov in (True, False):
     big = torch.randn(1 << 24).cuda()
     g.replay(); print("  replay after one big H2D copy: %.6f  |grad| %.6f" % (float(out), float(gc.float().norm())), flush=True)
     del junk, junk2, big
+
+# ---- node inventory of the loss-only graph (what does rocPRIM put into a capture?)
+a, b, c = (t.clone().requires_grad_(True) for t in (s1, d, s2))
+st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(st):
+    ops.train_loss(a, b, c, seg, disp, True)
+torch.cuda.current_stream().wait_stream(st)
+g = torch.cuda.CUDAGraph()
+g.enable_debug_mode()
+with torch.cuda.graph(g):
+    out = ops.train_loss(a, b, c, seg, disp, True)
+os.makedirs("gpurun_out", exist_ok=True)
+g.debug_dump("gpurun_out/r2_lossgraph.dot")
+txt = open("gpurun_out/r2_lossgraph.dot").read()
+import re, collections
+kinds = collections.Counter(re.findall(r'label="([A-Za-z_ ]+)', txt))
+print("graph node labels:", dict(kinds), flush=True)
+for line in txt.splitlines():
+    if "MEMCPY" in line.upper() or "memcpy" in line or "MEMSET" in line.upper():
+        print("   ", line.strip()[:300], flush=True)

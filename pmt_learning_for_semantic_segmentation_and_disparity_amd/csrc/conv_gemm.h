@@ -6,7 +6,7 @@
 // a ridge of ~310): the job is to keep HBM busy, not the matrix cores.  The halo-tile kernel of conv_fast.h stages one
 // channel chunk, waits, multiplies one tap, waits again — with one tap per chunk nothing hides the load latency.  Here:
 //
-//   * persistent workgroups (one or two per CU) walk a contiguous range of (cout block, 128-pixel tile) pairs and run ONE
+//   * persistent 8-wave workgroups (one per CU) walk a contiguous range of (cout block, 256-pixel tile) pairs and run ONE
 //     continuous software pipeline over all their (tile, 64-channel chunk) stages: an NS-deep LDS ring filled by LDS-DMA
 //     (`global_load_lds_dwordx4`: no VGPR round trip), NS-1 stages in flight across tile boundaries and epilogues, a
 //     counted `s_waitcnt vmcnt(n)` + raw `s_barrier` per stage (never a full drain);
@@ -44,153 +44,147 @@ struct GemmArgs {
   long ppg;               // pixels per statistics group
   int stats_ld, nrep; long rep_stride;
   int ntiles, nblk;       // 128-pixel tiles, cout blocks
+  int dbg;                // diagnostics (SDHIP_TUNE_GEMM_DBG): 1 no stores, 2 weights fetched once per workgroup, 4 no MFMA
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// 512 threads = 8 waves: wave w owns pixel rows [32w, 32w + 32) of the 256-pixel tile and all NT output channels.
+// Everything in the stage loop is 32-bit and incremental (no division, no 64-bit multiply): with one or two waves per SIMD
+// the loop's own instruction stream is what competes with the DMA for time.
 template <int NT, int NS>
-__global__ __launch_bounds__(256) void gemm1x1_kernel(const GemmArgs p) {
-  constexpr int MT = 128, NT_CO = NT / 16, NT_PIX = 2;
-  constexpr int A_BYTES = MT * 128, W_BYTES = NT * 128, ST_BYTES = A_BYTES + W_BYTES;
-  constexpr int A_INSTR = MT / 32, W_INSTR = NT / 32, IPS = A_INSTR + W_INSTR;   // DMA instructions per wave per stage
+__global__ __launch_bounds__(512) void gemm1x1_kernel(const GemmArgs p) {
+  constexpr int MT = 256, NT_CO = NT / 16, NT_PIX = 2;
+  constexpr int WROWS = NT < 64 ? 64 : NT;        // a DMA round is 64 rows: narrow blocks pad their weight tile to one round
+  constexpr int A_BYTES = MT * 128, W_BYTES = WROWS * 128, ST_BYTES = A_BYTES + W_BYTES;
+  constexpr int A_INSTR = MT / 64, W_INSTR = WROWS / 64, IPS = A_INSTR + W_INSTR;   // DMA instructions per wave per stage (same for every wave)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int nq = (p.K + 63) >> 6;
   unsigned char* const ring = smem;
-  float* const tab = reinterpret_cast<float*>(smem + NS * ST_BYTES);   // [2][nq*64]: scale, shift of the current group
-  float* const red = tab + 2 * nq * 64;                                 // [4 waves][2][NT]
+  float* const red = reinterpret_cast<float*>(smem + NS * ST_BYTES);   // [2][NT] statistics of the workgroup (LDS atomics)
+  float* const tab = red + 2 * NT;                                      // [2][nq*64]: scale, shift of the current group (prologue only)
 
   // contiguous range of virtual tiles v = nb * ntiles + t for this workgroup
-  const long nvt = (long)p.ntiles * p.nblk;
-  const long per = (nvt + gridDim.x - 1) / gridDim.x;
-  const long v0 = (long)blockIdx.x * per;
-  const long v1 = v0 + per < nvt ? v0 + per : nvt;
+  const int nvt = p.ntiles * p.nblk;
+  const int per = (nvt + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int v0 = (int)blockIdx.x * per;
+  const int v1 = v0 + per < nvt ? v0 + per : nvt;
   if (v0 >= v1) return;
-  const long nst = (v1 - v0) * nq;
+  const int nst = (v1 - v0) * nq;
 
   // ---- DMA side ----
-  const int rsub = tid >> 3;                      // row inside a 32-row round
+  const int rsub = tid >> 3;                      // row inside a 64-row round
   const int c_l = (tid & 7) ^ (rsub & 6);         // logical 16-byte piece this lane fetches (swizzle on the source side)
   const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);
   const bf16_t* const wpk = (const bf16_t*)p.wp;
-  long iv = v0; int iq = 0;                       // next stage to issue
-  const bf16_t* arow[2][A_INSTR];                 // per segment, per round: this lane's source row (nullptr: outside)
-  long i_t = -1;
-  auto tile_rows = [&](long t) {
+  int i_nb = v0 / p.ntiles, i_t = v0 - i_nb * p.ntiles, i_q = 0, i_slot = 0;   // next stage to issue
+  const bf16_t* arow0[A_INSTR];                   // this lane's source rows of the tile being issued (clamped to a valid pixel)
+  const bf16_t* arow1[A_INSTR];
+  auto tile_rows = [&](int t) {
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
-      const long pix = t * MT + j * 32 + rsub;
+      long pix = (long)t * MT + j * 64 + rsub;
+      pix = pix < p.M ? pix : p.M - 1;           // rows past the last pixel re-read it: their results are never stored
 #pragma unroll
       for (int sgi = 0; sgi < 2; ++sgi) {
-        arow[sgi][j] = nullptr;
-        if (sgi < p.nseg && pix < p.M) {
+        const bf16_t* r = (const bf16_t*)sdhip_zero16;
+        if (sgi < p.nseg) {
           long sp = pix;
           const int us = p.seg[sgi].us;
           if (us) {
-            const long hw = (long)p.H * p.W;
-            const long b = pix / hw;
-            const int r = (int)(pix - b * hw);
-            const int h = r / p.W, w = r - h * p.W;
-            sp = (b * (p.H >> us) + (h >> us)) * (p.W >> us) + (w >> us);
+            const unsigned hw = (unsigned)(p.H * p.W);
+            const unsigned b = (unsigned)pix / hw;
+            const unsigned rr = (unsigned)pix - b * hw;
+            const unsigned h = rr / (unsigned)p.W, w = rr - h * (unsigned)p.W;
+            sp = ((long)b * (p.H >> us) + (h >> us)) * (p.W >> us) + (w >> us);
           }
-          arow[sgi][j] = (const bf16_t*)p.seg[sgi].p + sp * p.seg[sgi].ld;
+          r = (const bf16_t*)p.seg[sgi].p + sp * p.seg[sgi].ld;
         }
+        if (sgi == 0) arow0[j] = r; else arow1[j] = r;
       }
     }
   };
-  auto issue = [&](long st) {
-    const int nb = (int)(iv / p.ntiles);
-    const long t = iv - (long)nb * p.ntiles;
-    if (t != i_t) { tile_rows(t); i_t = t; }
-    const unsigned dst = (unsigned)((st % NS) * ST_BYTES) + wave_lds;
-    const int k0 = iq * 64 + c_l * 8;
-    const int c0 = p.seg[0].c;
-    const int sgi = k0 < c0 ? 0 : 1;
-    const int kk = sgi ? k0 - c0 : k0;
-    const bool kin = sgi < p.nseg && kk < p.seg[sgi].c;
+  tile_rows(i_t);
+  const int c0 = p.seg[0].c, c1 = p.nseg > 1 ? p.seg[1].c : 0;
+  auto issue = [&]() {
+    const unsigned dst = (unsigned)(i_slot * ST_BYTES) + wave_lds;
+    const int k0 = i_q * 64 + c_l * 8;
+    const bool s1 = k0 >= c0;
+    const int kk = s1 ? k0 - c0 : k0;
+    const bool kin = s1 ? kk < c1 : true;        // pieces past the last channel read the zero block
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
-      const bf16_t* row = sgi ? arow[1][j] : arow[0][j];
-      const void* src = (kin && row) ? (const void*)(row + kk) : (const void*)sdhip_zero16;
-      glds16(src, dst + j * 4096);
+      const bf16_t* row = s1 ? arow1[j] : arow0[j];
+      const void* src = kin ? (const void*)(row + kk) : (const void*)sdhip_zero16;
+      glds16(src, dst + j * 8192);
     }
-    const int n0 = nb * NT;
+    const int n0 = i_nb * NT;
     const int mvalid = p.Mpad - n0 < NT ? p.Mpad - n0 : NT;
-    const bf16_t* wb = wpk + ((long)iq * p.Mpad + n0) * 64 + c_l * 8;
+    const bf16_t* wb = wpk + ((long)i_q * p.Mpad + n0) * 64 + c_l * 8;
 #pragma unroll
     for (int j = 0; j < W_INSTR; ++j) {
-      int m = j * 32 + rsub;
+      int m = j * 64 + rsub;
       m = m < mvalid ? m : mvalid - 1;           // rows past Mpad are never stored: re-read a valid row
-      glds16(wb + m * 64, dst + A_BYTES + j * 4096);
+      if (!(p.dbg & 16)) glds16(wb + m * 64, dst + A_BYTES + j * 8192);
     }
-    if (++iq == nq) { iq = 0; ++iv; }
+    if (++i_slot == NS) i_slot = 0;
+    if (++i_q == nq) {
+      i_q = 0;
+      if (++i_t == p.ntiles) { i_t = 0; ++i_nb; }
+      tile_rows(i_t);
+    }
   };
 
   // ---- compute side ----
   f32x4 acc[NT_CO][NT_PIX];
-  float s1[NT_CO][4], s2[NT_CO][4];
-#pragma unroll
-  for (int mi = 0; mi < NT_CO; ++mi)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
-  const int a_off = LdsRow<2>::off(l15, lg);                    // weight rows mi*16 + l15
+  const int a_off = LdsRow<2>::off(l15, lg);                       // weight rows mi*16 + l15
   const int b_off = (wave * 32) * 128 + LdsRow<2>::off(l15, lg);   // pixel rows wave*32 + ni*16 + l15
-  const bool tailk = (p.K & 7) != 0;
+  const bool tailk = (p.K & 63) != 0;             // the last chunk holds pieces past K (zero block) or a partial piece
   int cur_grp = -1, st_grp = -1, st_nb = -1;      // group whose table is loaded; (group, block) of the pending statistics
-  long cv = v0; int cq = 0;
+  int c_nb = v0 / p.ntiles, c_t = v0 - c_nb * p.ntiles, c_q = 0, c_slot = 0;
+  const int tiles_per_grp = p.ppg > 0 ? (int)(p.ppg / MT) : 0x7fffffff;
 
   auto load_table = [&](int g) {                 // all threads; callers bracket it with barriers
-    for (int k = tid; k < nq * 64; k += 256) {
+    for (int k = tid; k < nq * 64; k += 512) {
       const bool in = k < p.K;
       tab[k] = in ? p.in_scale[(long)g * p.K + k] : 0.f;
       tab[nq * 64 + k] = in ? p.in_shift[(long)g * p.K + k] : 0.f;
     }
   };
+  // statistics: every tile's epilogue adds its column sums into `red` (LDS atomics); one global flush per (group, block)
   auto flush_stats = [&]() {                     // all threads
-    __syncthreads();
-#pragma unroll
-    for (int mi = 0; mi < NT_CO; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float a = row16_sum(s1[mi][r]), c2 = row16_sum(s2[mi][r]);
-        if (l15 == 0) {
-          const int m = mi * 16 + 4 * lg + r;
-          red[(wave * 2 + 0) * NT + m] = a;
-          red[(wave * 2 + 1) * NT + m] = c2;
-        }
-        s1[mi][r] = 0.f; s2[mi][r] = 0.f;
-      }
     __syncthreads();
     if (tid < 2 * NT) {
       const int which = tid / NT, m = tid - which * NT;
       const int co = st_nb * NT + m;
-      if (co < p.Cout) {
-        const float tot = red[(0 * 2 + which) * NT + m] + red[(1 * 2 + which) * NT + m] + red[(2 * 2 + which) * NT + m] +
-                          red[(3 * 2 + which) * NT + m];
-        atomicAdd(p.stats + (long)(blockIdx.x % p.nrep) * p.rep_stride + ((long)st_grp * 2 + which) * p.stats_ld + co, (double)tot);
-      }
+      if (co < p.Cout)
+        atomicAdd(p.stats + (long)(blockIdx.x % p.nrep) * p.rep_stride + ((long)st_grp * 2 + which) * p.stats_ld + co, (double)red[tid]);
+      red[tid] = 0.f;
     }
+    __syncthreads();
   };
+  if (p.stats) {
+    if (tid < 2 * NT) red[tid] = 0.f;             // published by the first stage barrier
+  }
 
   // ---- prime the ring ----
   {
-    const long pre = nst < NS - 1 ? nst : NS - 1;
-    for (long s = 0; s < pre; ++s) issue(s);
+    const int pre = nst < NS - 1 ? nst : NS - 1;
+    for (int s = 0; s < pre; ++s) issue();
   }
 
-  for (long st = 0; st < nst; ++st) {
-    const int nb = (int)(cv / p.ntiles);
-    const long t = cv - (long)nb * p.ntiles;
-    if (cq == 0) {
+  for (int st = 0; st < nst; ++st) {
+    if (c_q == 0) {
 #pragma unroll
       for (int mi = 0; mi < NT_CO; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NT_PIX; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int grp = p.ppg > 0 ? (int)((t * MT) / p.ppg) : 0;
-      if (p.stats && (grp != st_grp || nb != st_nb)) {
+      const int grp = c_t >= tiles_per_grp ? c_t / tiles_per_grp : 0;
+      if (p.stats && (grp != st_grp || c_nb != st_nb)) {
         if (st_grp >= 0) flush_stats();
-        st_grp = grp; st_nb = nb;
+        st_grp = grp; st_nb = c_nb;
       }
       if (p.in_scale && grp != cur_grp) {
         __syncthreads();                          // nobody still reads the previous group's table
@@ -199,23 +193,26 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const GemmArgs p) {
       }
     }
     // stage st has landed when at most the DMA instructions of the younger in-flight stages are outstanding
-    const long younger = nst - 1 - st < NS - 2 ? nst - 1 - st : NS - 2;
-    if (younger >= 2) wait_vm<2 * IPS>(); else if (younger == 1) wait_vm<IPS>(); else wait_vm<0>();
+    const int younger = nst - 1 - st < NS - 2 ? nst - 1 - st : NS - 2;
+    if (p.dbg & 16) { if (younger >= 2) wait_vm<2 * A_INSTR>(); else if (younger == 1) wait_vm<A_INSTR>(); else wait_vm<0>(); }
+    else if (younger >= 2) wait_vm<2 * IPS>(); else if (younger == 1) wait_vm<IPS>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();                 // every wave's part of stage st is in LDS; stage st-1's slot is free
-    if (st + NS - 1 < nst) issue(st + NS - 1);
+    if (st + NS - 1 < nst) issue();
 
-    const unsigned char* const abuf = ring + (st % NS) * ST_BYTES;
+    const unsigned char* const abuf = ring + c_slot * ST_BYTES;
     const unsigned char* const wbuf = abuf + A_BYTES;
-    const bool xform = p.in_scale != nullptr || (tailk && cq == nq - 1);
+    const bool last = c_q == nq - 1;
+    const bool xform = p.in_scale != nullptr || (tailk && last);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if (p.dbg & 8) break;
       u32x4 af[NT_CO], bf[NT_PIX];
 #pragma unroll
       for (int mi = 0; mi < NT_CO; ++mi) af[mi] = *reinterpret_cast<const u32x4*>(wbuf + ((a_off + mi * 2048) ^ (ks << 6)));
 #pragma unroll
       for (int ni = 0; ni < NT_PIX; ++ni) bf[ni] = *reinterpret_cast<const u32x4*>(abuf + ((b_off + ni * 2048) ^ (ks << 6)));
       if (xform) {                                // wave-uniform
-        const int kb = cq * 64 + ks * 32 + lg * 8;
+        const int kb = c_q * 64 + ks * 32 + lg * 8;
         float sc[8], sh[8];
         if (p.in_scale) {
           const f32x4 a0 = *reinterpret_cast<const f32x4*>(tab + kb), a1 = *reinterpret_cast<const f32x4*>(tab + kb + 4);
@@ -227,28 +224,40 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const GemmArgs p) {
           for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
         }
         const int nv = p.K - kb;                  // valid channels of this 8-channel piece
+        const bool whole = c_q * 64 + ks * 32 + 32 <= p.K;   // wave-uniform: no lane of this k-step holds channels past K
 #pragma unroll
         for (int ni = 0; ni < NT_PIX; ++ni) {
           float f[8];
           Chunk<bf16_t>::unpack(bf[ni], f);
+          if (whole) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float v = fmaf(f[e], sc[e], sh[e]);
-            if (p.in_relu) v = fmaxf(v, 0.f);
-            f[e] = e < nv ? v : 0.f;
+            for (int e = 0; e < 8; ++e) {
+              const float v = fmaf(f[e], sc[e], sh[e]);
+              f[e] = p.in_relu ? fmaxf(v, 0.f) : v;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float v = fmaf(f[e], sc[e], sh[e]);
+              if (p.in_relu) v = fmaxf(v, 0.f);
+              f[e] = e < nv ? v : 0.f;
+            }
           }
           bf[ni] = Chunk<bf16_t>::pack(f);
         }
       }
+      if (!(p.dbg & 4)) {
 #pragma unroll
-      for (int mi = 0; mi < NT_CO; ++mi)
+        for (int mi = 0; mi < NT_CO; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NT_PIX; ++ni) Mma<bf16_t>::run(acc[mi][ni], af[mi], bf[ni]);
+          for (int ni = 0; ni < NT_PIX; ++ni) Mma<bf16_t>::run(acc[mi][ni], af[mi], bf[ni]);
+      }
     }
+    if (++c_slot == NS) c_slot = 0;
 
-    if (cq == nq - 1) {
-      // ---- epilogue of tile (nb, t) ----
-      const int n0 = nb * NT;
+    if (last) {
+      // ---- epilogue of tile (c_nb, c_t) ----
+      const int n0 = c_nb * NT;
       if (p.bias) {
 #pragma unroll
         for (int mi = 0; mi < NT_CO; ++mi) {
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const GemmArgs p) {
       bf16_t* const yb = (bf16_t*)p.y;
 #pragma unroll
       for (int ni = 0; ni < NT_PIX; ++ni) {
-        const long pix = t * MT + wave * 32 + ni * 16 + l15;
+        const long pix = (long)c_t * MT + wave * 32 + ni * 16 + l15;
         const bool pv = pix < p.M;
         bf16_t* const dst = yb + pix * p.ldy + n0 + 4 * lg;
 #pragma unroll
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const GemmArgs p) {
           const u32x2 o = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
           v = f32x4{bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1])};      // statistics of the STORED values
           if (pv && co + 3 < p.Cout) {
-            *reinterpret_cast<u32x2*>(dst + mi * 16) = o;
+            if (!(p.dbg & 1)) *reinterpret_cast<u32x2*>(dst + mi * 16) = o;
           } else if (pv && co < p.Cout) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -294,25 +303,42 @@ __global__ __launch_bounds__(256) void gemm1x1_kernel(const GemmArgs p) {
           } else {
             v = f32x4{0.f, 0.f, 0.f, 0.f};
           }
-          if (p.stats) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s1[mi][r] += v[r]; s2[mi][r] = fmaf(v[r], v[r], s2[mi][r]); }
-          }
+          acc[mi][ni] = v;                         // what was stored (zero where nothing was)
         }
       }
-      cq = 0; ++cv;
+      if (p.stats) {                              // uniform: column sums of the tile -> LDS
+#pragma unroll
+        for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v0 = acc[mi][0][r], v1 = acc[mi][1][r];
+            const float a = row16_sum(v0 + v1), c2 = row16_sum(fmaf(v0, v0, v1 * v1));
+            if (l15 == 0) {
+              const int m = mi * 16 + 4 * lg + r;
+              atomicAdd(red + m, a);
+              atomicAdd(red + NT + m, c2);
+            }
+          }
+      }
+      c_q = 0;
+      if (++c_t == p.ntiles) { c_t = 0; ++c_nb; }
     } else {
-      ++cq;
+      ++c_q;
     }
   }
   if (p.stats && st_grp >= 0) flush_stats();
+}
+
+inline size_t gemm_lds_bytes(int nt, int ns, int nq, bool table) {
+  return (size_t)ns * (256 * 128 + (nt < 64 ? 64 : nt) * 128) + (size_t)2 * nt * 4 + (table ? (size_t)2 * nq * 64 * 4 : 0);
 }
 
 template <int NT, int NS>
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
   auto kern = gemm1x1_kernel<NT, NS>;
   const int nq = (a.K + 63) / 64;
-  const size_t lds = (size_t)NS * (128 * 128 + NT * 128) + (size_t)2 * nq * 64 * 4 + (size_t)4 * 2 * NT * 4;
+  const size_t lds = gemm_lds_bytes(NT, NS, nq, a.in_scale != nullptr);
+  if (lds > 160 * 1024) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "gemm1x1: %d input channels with a prologue do not fit the LDS table", a.K);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -323,34 +349,38 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   long grid = 256L * (per_cu > 2 ? 2 : per_cu);
   if (grid > nvt) grid = nvt;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, a);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }
 
 // Can this 1x1 convolution take the GEMM path?  (bf16, 16-byte aligned rows, whole statistics groups per tile range.)
 inline bool gemm1x1_ok(const GemmArgs& a, int groups) {
-  if (a.M < 4096 || a.K > 4096 || a.Mpad > 2048) return false;
+  // measured (tools/gpu_gemmdiag.py): the persistent 256-pixel tiles need >= 128 of them to keep every CU streaming; with
+  // fewer pixels the halo-tile kernel's many small workgroups win
+  if (a.M < 32768 || (a.M < 65536 && a.in_scale) || a.K > 4096 || a.Mpad > 2048) return false;
   for (int i = 0; i < a.nseg; ++i) {
     if (a.seg[i].ld % 8 || ((uintptr_t)a.seg[i].p & 15)) return false;
     if (a.seg[i].us && ((a.H & ((1 << a.seg[i].us) - 1)) || (a.W & ((1 << a.seg[i].us) - 1)))) return false;
   }
   if (a.nseg == 2 && (a.seg[0].c % 8)) return false;
   if (a.ldy % 4 || ((uintptr_t)a.y & 7)) return false;
-  if (groups > 1 && (a.M % groups || (a.M / groups) % 128)) return false;   // a 128-pixel tile never straddles two groups
+  if (groups > 1 && (a.M % groups || (a.M / groups) % 256)) return false;   // a 256-pixel tile never straddles two groups
+  if (a.M >= (1L << 31) / 2) return false;
+  if (a.in_scale && a.K > 1024) return false;                               // prologue table: 8 KB next to a 144 KB ring
   return true;
 }
 
 inline int launch_gemm_any(GemmArgs& a, hipStream_t s) {
-  a.ntiles = (int)((a.M + 127) / 128);
-  // cout block: the widest that wastes at most a quarter of its MFMA rows
-  int nt = 32;
-  for (int cand = 128; cand >= 32; cand >>= 1)
-    if ((long)sdhip_cdiv(a.Mpad, cand) * cand * 4 <= (long)a.Mpad * 5) { nt = cand; break; }
+  a.ntiles = (int)((a.M + 255) / 256);
+  a.dbg = sdhip_diag().tune_gemm_dbg;
+  // cout block: these layers are bound by streaming the pixel rows, so one block should cover all output channels
+  // whenever it can (every extra block re-reads the rows); MFMA rows wasted on padding are free
+  const int nt = a.Mpad <= 32 ? 32 : (a.Mpad <= 64 ? 64 : 128);
   a.nblk = sdhip_cdiv(a.Mpad, nt);
-  if (nt == 128) return launch_gemm<128, 4>(a, s);
-  if (nt == 64) return launch_gemm<64, 4>(a, s);
-  return launch_gemm<32, 4>(a, s);
+  if (nt == 128) return launch_gemm<128, 3>(a, s);
+  if (nt == 64) return launch_gemm<64, 3>(a, s);
+  return launch_gemm<32, 3>(a, s);
 }
 
 }  // namespace

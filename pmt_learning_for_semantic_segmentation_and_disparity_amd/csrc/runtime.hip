@@ -42,6 +42,7 @@ static void diag_fill() {
   g_diag.tune_split = env_int("SDHIP_TUNE_SPLIT", 1024);
   g_diag.tune_thin_blocks = env_int("SDHIP_TUNE_THIN_BLOCKS", 1024);
   g_diag.tune_fused_blocks = env_int("SDHIP_TUNE_FUSED_BLOCKS", 768);
+  g_diag.tune_gemm_dbg = env_int("SDHIP_TUNE_GEMM_DBG", 0);
   g_diag.tune_atomic_tbs = getenv("SDHIP_TUNE_ATOMIC_TBS") ? atof(getenv("SDHIP_TUNE_ATOMIC_TBS")) : 1.3;
   g_diag_init = true;
 }

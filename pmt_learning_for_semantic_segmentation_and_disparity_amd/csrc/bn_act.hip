@@ -635,8 +635,8 @@ extern "C" int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int 
   SDHIP_CHECK_ARG((dscale == nullptr) == (dshift == nullptr), "affine_act_bwd: dscale/dshift must come together");
   hipStream_t s = (hipStream_t)stream;
   if (dscale && !prezeroed) {
-    if (hipMemsetAsync(dscale, 0, sizeof(float) * (size_t)nrep * G * C, s) != hipSuccess ||
-        hipMemsetAsync(dshift, 0, sizeof(float) * (size_t)nrep * G * C, s) != hipSuccess)
+    if (sdhip_zero_async(dscale, sizeof(float) * (size_t)nrep * G * C, s) != hipSuccess ||
+        sdhip_zero_async(dshift, sizeof(float) * (size_t)nrep * G * C, s) != hipSuccess)
       SDHIP_FAIL(SDHIP_ERR_LAUNCH, "affine_act_bwd: memset failed");
   }
 #define ARGS(T) (const T*)gy, ldg, (const T*)x, ldx, (T*)gx, ldgx, scale, shift, dscale, dshift, nrep, C, npix / G, act, accumulate

@@ -415,8 +415,8 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
   hipStream_t s = (hipStream_t)stream;
   const long n = (long)kd * sdhip_conv_packed_elems(Cout, Cin, T, dtype);
   if (!prezeroed) {
-    if (hipMemsetAsync(dw_packed, 0, n * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
-    if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
+    if (sdhip_zero_async(dw_packed, n * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
+    if (dbias && sdhip_zero_async(dbias, (size_t)Cout * sizeof(float), s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: memset failed");
   }
   // ---- thin path (conv_thin.h): <= 8 input channels -> 1 output channel ----
   if (Cout == 1 && Cin <= V && a.vec_x && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale && T <= 25 &&

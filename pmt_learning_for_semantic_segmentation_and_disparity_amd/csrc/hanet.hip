@@ -153,7 +153,7 @@ extern "C" int sdhip_rowpool_max_bwd(const void* gy, int ldg, const int* idx, vo
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "rowpool_max_bwd: unknown dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
   const size_t es = dtype == SDHIP_BF16 ? 2 : 4;
-  if (hipMemsetAsync(gx, 0, (size_t)B * H * W * ldgx * es, s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "rowpool_max_bwd: memset failed");
+  if (sdhip_zero_async(gx, (size_t)B * H * W * ldgx * es, s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "rowpool_max_bwd: memset failed");
   const long total = (long)B * C;
   if (dtype == SDHIP_F32) hipLaunchKernelGGL(rowpool_max_bwd_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, s, (const float*)gy, ldg, idx, (float*)gx, ldgx, H, W, C, OH, total);
   else hipLaunchKernelGGL(rowpool_max_bwd_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, s, (const bf16_t*)gy, ldg, idx, (bf16_t*)gx, ldgx, H, W, C, OH, total);

@@ -16,6 +16,11 @@ using std::memset;
 
 namespace {
 
+// rocPRIM sorts up to 1 Mi keys with its merge sort and larger inputs with the one-sweep radix sort, which clears its
+// histograms with hipMemsetAsync — memset nodes once the step is captured, and those are not reliable under hipGraph
+// replay on ROCm 7.2 (sdhip_common.h, sdhip_zero_async).  The merge path launches kernels only: it is used at every size.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t)1 << 40>;
+
 struct FgFlag {
   __device__ __host__ unsigned int operator()(unsigned int v) const { return v >> 31; }
 };
@@ -161,7 +166,7 @@ Layout layout(long npix, int C) {
   L.counts = off; off = al(off + (size_t)(C + 1) * 4);
   L.lossc = off; off = al(off + (size_t)C * 8);
   size_t t1 = 0, t2 = 0;
-  (void)rocprim::radix_sort_pairs_desc(nullptr, t1, (const float*)nullptr, (float*)nullptr, (const unsigned int*)nullptr,
+  (void)rocprim::radix_sort_pairs_desc<SortConfig>(nullptr, t1, (const float*)nullptr, (float*)nullptr, (const unsigned int*)nullptr,
                                  (unsigned int*)nullptr, (size_t)npix);
   auto it = rocprim::make_transform_iterator((const unsigned int*)nullptr, FgFlag());
   (void)rocprim::inclusive_scan(nullptr, t2, it, (unsigned int*)nullptr, (size_t)npix, rocprim::plus<unsigned int>());
@@ -211,7 +216,8 @@ extern "C" int sdhip_lovasz_softmax(const void* logits, int ldy, const float* ta
   float* gerr = (float*)(ws + L.gerr);
   unsigned int* counts = (unsigned int*)(ws + L.counts);
   double* lossc = (double*)(ws + L.lossc);
-  if (hipMemsetAsync(ws + L.counts, 0, L.temp - L.counts, s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "lovasz_softmax: memset failed");
+  // (a kernel, not hipMemsetAsync: the step is replayed from a hipGraph, and everything in it is kept to kernel nodes)
+  if (sdhip_zero_async(ws + L.counts, L.temp - L.counts, s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "lovasz_softmax: clearing the counters failed");
   if (dtype == SDHIP_F32)
     hipLaunchKernelGGL(lovasz_errors_kernel<float>, grid_for(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, keys_in, vals_in, counts, npix, C);
   else
@@ -219,7 +225,7 @@ extern "C" int sdhip_lovasz_softmax(const void* logits, int ldy, const float* ta
   for (int c = 0; c < C; ++c) {
     size_t tb = L.temp_bytes;
     const size_t o = (size_t)c * npix;
-    if (rocprim::radix_sort_pairs_desc(ws + L.temp, tb, keys_in + o, keys_out + o, vals_in + o, vals_out + o, (size_t)npix, 0, 32, s) != hipSuccess)
+    if (rocprim::radix_sort_pairs_desc<SortConfig>(ws + L.temp, tb, keys_in + o, keys_out + o, vals_in + o, vals_out + o, (size_t)npix, 0, 32, s) != hipSuccess)
       SDHIP_FAIL(SDHIP_ERR_LAUNCH, "lovasz_softmax: radix sort failed");
     tb = L.temp_bytes;
     auto it = rocprim::make_transform_iterator((const unsigned int*)(vals_out + o), FgFlag());

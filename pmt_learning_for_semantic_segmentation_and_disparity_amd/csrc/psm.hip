@@ -277,7 +277,7 @@ extern "C" int sdhip_stuff(const void* src, int lds_, void* dst, int ldd, int N,
   const int es = dtype == SDHIP_BF16 ? 2 : 4;
   if (scatter) {
     SDHIP_CHECK_ARG(ldd == C, "stuff: the zero-stuffed output must be dense");
-    if (hipMemsetAsync(dst, 0, (size_t)N * Ds * Hs * Ws * C * es, st) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "stuff: memset failed");
+    if (sdhip_zero_async(dst, (size_t)N * Ds * Hs * Ws * C * es, st) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "stuff: memset failed");
   }
 #define GO(T, V) do { if (scatter) hipLaunchKernelGGL((stuff_kernel<T, V, true>), grid_for(np * (V ? C / Chunk<T>::N : C)), dim3(256), 0, st, (const T*)src, (T*)dst, dense, stuffed, sd, s); \
                       else hipLaunchKernelGGL((stuff_kernel<T, V, false>), grid_for(np * (V ? C / Chunk<T>::N : C)), dim3(256), 0, st, (const T*)src, (T*)dst, dense, stuffed, sd, s); } while (0)
@@ -341,7 +341,7 @@ extern "C" int sdhip_softargmin_bwd(const void* cost, const void* gpred, void* g
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "softargmin_bwd: unknown dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
   const long nv = (long)B * D4 * H4 * W4, np = (long)B * H * W;
-  if (hipMemsetAsync(gcost_f32, 0, nv * sizeof(float), st) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "softargmin_bwd: memset failed");
+  if (sdhip_zero_async(gcost_f32, nv * sizeof(float), st) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "softargmin_bwd: memset failed");
   const size_t sa_lds = ((size_t)kMaxD4 * 256 + (size_t)kMaxD4 * kSaCells) * sizeof(float);
   static bool sa_attr = false;
   if (!sa_attr) {

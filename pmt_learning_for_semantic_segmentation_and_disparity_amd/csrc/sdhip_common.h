@@ -115,3 +115,33 @@ template <typename T, bool VEC> struct Unit {
 };
 
 static inline int sdhip_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- zero fill as a KERNEL ------------------------------------------------------------------------------------------
+// hipMemsetAsync becomes a memset node when the training step is captured into a hipGraph, and on ROCm 7.2 such a node
+// was observed to stop clearing its 512-byte target once unrelated allocations had been made between two replays (the
+// Lovasz class counters then accumulated from replay to replay: tests/diag/gpu_lovasz_graph.py).  Everything the
+// library clears on a stream is therefore cleared by this kernel: a captured step consists of kernel nodes only.
+namespace {
+__global__ __launch_bounds__(256) void sdhip_zero_kernel(unsigned int* __restrict__ p, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if ((((uintptr_t)p) & 15) == 0) {
+    u32x4* p16 = reinterpret_cast<u32x4*>(p);
+    const size_t n16 = n4 >> 2;
+    for (size_t j = i; j < n16; j += stride) p16[j] = u32x4{0u, 0u, 0u, 0u};
+    for (size_t j = (n16 << 2) + i; j < n4; j += stride) p[j] = 0u;
+  } else {
+    for (size_t j = i; j < n4; j += stride) p[j] = 0u;
+  }
+}
+inline hipError_t sdhip_zero_async(void* ptr, size_t bytes, hipStream_t s) {   // ptr 4-byte aligned, bytes a multiple of 2
+  if (bytes == 0) return hipSuccess;
+  if ((((uintptr_t)ptr) & 3) || (bytes & 3)) return hipMemsetAsync(ptr, 0, bytes, s);   // (never on the hot path: all buffers are >= 4-byte multiples)
+  const size_t n4 = bytes >> 2;
+  size_t blocks = (n4 / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sdhip_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned int*)ptr, n4);
+  return hipGetLastError();
+}
+}  // namespace

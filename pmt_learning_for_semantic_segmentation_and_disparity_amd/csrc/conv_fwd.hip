@@ -586,6 +586,6 @@ extern "C" int sdhip_conv1x1_cat_fwd(const void* x0, int ld0, int c0, int us0, c
   g.ldy = ldy; g.Cout = Cout; g.Mpad = (Cout + 15) & ~15; g.K = c0 + c1; g.in_relu = 0; g.act = act;
   g.M = (long)B * H * W; g.H = H; g.W = W; g.ppg = g.M;
   g.stats_ld = Cout; g.nrep = 1; g.rep_stride = 0;
-  if (!gemm1x1_ok(g, 1)) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv1x1_cat_fwd: operands not 16-byte aligned / grid not divisible by the upsampling factor");
+  if (!gemm1x1_ok(g, 1, true)) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv1x1_cat_fwd: operands not 16-byte aligned / grid not divisible by the upsampling factor");
   return launch_gemm_any(g, (hipStream_t)stream);
 }

@@ -355,10 +355,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
 }
 
 // Can this 1x1 convolution take the GEMM path?  (bf16, 16-byte aligned rows, whole statistics groups per tile range.)
-inline bool gemm1x1_ok(const GemmArgs& a, int groups) {
+inline bool gemm1x1_ok(const GemmArgs& a, int groups, bool any_size = false) {
   // measured (tools/gpu_gemmdiag.py): the persistent 256-pixel tiles need >= 128 of them to keep every CU streaming; with
   // fewer pixels the halo-tile kernel's many small workgroups win
-  if (a.M < 32768 || (a.M < 65536 && a.in_scale) || a.K > 4096 || a.Mpad > 2048) return false;
+  if (!any_size && (a.M < 32768 || (a.M < 65536 && a.in_scale))) return false;
+  if (a.K > 4096 || a.Mpad > 2048) return false;
   for (int i = 0; i < a.nseg; ++i) {
     if (a.seg[i].ld % 8 || ((uintptr_t)a.seg[i].p & 15)) return false;
     if (a.seg[i].us && ((a.H & ((1 << a.seg[i].us) - 1)) || (a.W & ((1 << a.seg[i].us) - 1)))) return false;

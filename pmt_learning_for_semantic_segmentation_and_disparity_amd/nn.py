@@ -256,8 +256,9 @@ class segNet(nn.Module):
         x = ops.interpolate(x, scale_factor=2, mode='nearest')
         x = self.Conv2DownUp1(self.conv1d_1[0].run(x, act=1))
         x1 = ops.interpolate(x, scale_factor=2, mode='nearest')
-        s = ops.interpolate(x, size=xleft.shape[2:], mode='nearest')
-        s = self.conv1d_2[0].run(ops.concat([s, xleft]), act=1)
+        s = ops.upcat_conv1x1(x, xleft, self.conv1d_2[0].c2d.weight, act=1)
+        if s is None:
+            s = self.conv1d_2[0].run(ops.concat([ops.interpolate(x, size=xleft.shape[2:], mode='nearest'), xleft]), act=1)
         s = self.Conv2DownUp2[1](self.Conv2DownUp2[0](s))
         return x, x1, ops.interpolate(s, size=input_a.shape[2:], mode='nearest')
 
@@ -358,9 +359,12 @@ class minidsnetExt(nn.Module):
         y1 = self.Conv2DownUp3(a[5] if 'no_dec1' in self.abilation else x1)
         y1 = ops.interpolate(y1, size=y.shape[2:], mode='bilinear')
         y = self.Conv2DownUp4(ops.concat([y1, y]))
-        y2 = ops.interpolate(y, scale_factor=8)
-        xl2 = ops.interpolate(xl2, size=y2.shape[2:], mode='bilinear')
-        d = self.Conv2DownUp5(self.conv1d_2[0].run(ops.concat([y2, xl2]), act=1))
+        up8 = (8 * y.shape[2], 8 * y.shape[3])
+        xl2 = ops.interpolate(xl2, size=up8, mode='bilinear')
+        d0 = ops.upcat_conv1x1(y, xl2, self.conv1d_2[0].c2d.weight, act=1)     # x8 upsample + concat folded into the 1x1 (bf16)
+        if d0 is None:
+            d0 = self.conv1d_2[0].run(ops.concat([ops.interpolate(y, scale_factor=8), xl2]), act=1)
+        d = self.Conv2DownUp5(d0)
         disp = ops.interpolate(self.dispoutConv(d), size=input_a.shape[2:], mode='bilinear')
 
         if self.aspp_mod == 1:
@@ -390,8 +394,9 @@ class minidsnetExt(nn.Module):
             seg2 = self.Conv2DownUp11[1](self.Conv2DownUp11[0](seg2))
             seg2 = ops.interpolate(seg2, size=input_a.shape[2:], mode='nearest')
         else:
-            s2 = ops.concat([ops.interpolate(s2, size=xl1.shape[2:]), xl1])
-            seg2 = self.conv1d_5[0].run(s2, act=1)
+            seg2 = ops.upcat_conv1x1(s2, xl1, self.conv1d_5[0].c2d.weight, act=1)
+            if seg2 is None:
+                seg2 = self.conv1d_5[0].run(ops.concat([ops.interpolate(s2, size=xl1.shape[2:]), xl1]), act=1)
             seg2 = self.Conv2DownUp11[0](seg2)
             if self.convDeconvOut:
                 s = self.convOutput2(seg2)

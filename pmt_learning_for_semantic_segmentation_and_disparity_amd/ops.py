@@ -705,6 +705,72 @@ def conv1x1_cat_forward(segs, weight, bias, act):
     return y
 
 
+class _UpCatConv1x1Fn(torch.autograd.Function):
+    """y = act(conv1x1(cat([nearest_upsample(xs, 2^us), xf], dim=1))) — `conv1d_2(torch.cat((F.interpolate(y, scale_factor=8),
+    xleft2), 1))` and its siblings (models/dsnet_t2.py:1211-1216,1262-1291,927-933) as one kernel: neither the upsampled
+    map nor the concatenation is ever written.  The backward pass never touches the upsampled form either:
+      grad(xs)      = dgrad1x1(sum-pool_{2^us}(g), W)[:, :c0]        (pooling and the 1x1 contraction commute)
+      grad(xf)      = conv1x1(g, W[:, c0:]^T)
+      dW[:, :c0]    = wgrad(xs, sum-pool(g)),   dW[:, c0:] = wgrad(xf, g)."""
+
+    @staticmethod
+    def forward(ctx, xs, xf, weight, us, act):
+        _require_gpu(xs, xf, weight)
+        y = conv1x1_cat_forward([(xs, us), (xf, 0)], weight, None, act)
+        ctx.save_for_backward(xs, xf, weight, y if act else None)
+        ctx.cfg = (us, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xs, xf, weight, ysaved = ctx.saved_tensors
+        us, act = ctx.cfg
+        B, Cout, H, W = gy.shape
+        c0, c1 = xs.shape[1], xf.shape[1]
+        h, w = xs.shape[2], xs.shape[3]
+        dt = dtype_code(gy)
+        g, ldg = aligned_view(gy)
+        if act:
+            g2, ldg2 = alloc_nhwc(B, Cout, H, W, gy.dtype, gy.device)
+            call("sdhip_affine_act_bwd", ptr(g), ldg, ptr(ysaved), nhwc_view(ysaved)[1], ptr(g2), ldg2, None, None, None, None, 1,
+                 B * H * W, Cout, 1, 1 if act == 1 else 4, 0, 0, dt, stream_ptr())
+            g, ldg = g2, ldg2
+        k = 1 << us
+        gp = avgpool(g, k)                                   # mean over the 2^us x 2^us block; the sum is k*k times that
+        gpv, ldgp = aligned_view(gp)
+        # gradient of the small map
+        wd = packed_weight(weight, 'conv', 'dgrad', gy.dtype)
+        gsm, ldgs = alloc_nhwc(B, c0 + c1, h, w, gy.dtype, gy.device)
+        _conv_launch(gpv, ldgp, wd, gsm, ldgs, None, None, None, None, B, h, w, Cout, h, w, c0 + c1, 1, 1, 1, 1, 0, 0, False, 1, 0, False)
+        gxs = affine_act(gsm[:, :c0], _const_vec(float(k * k), c0, gy.device), None, None, 0)
+        # gradient of the full-resolution segment: a Cout -> c1 1x1 convolution with W[:, c0:]^T
+        w_f = weight.detach()[:, c0:].transpose(0, 1).contiguous()
+        gxf, ldgf = alloc_nhwc(B, c1, H, W, gy.dtype, gy.device)
+        _conv_launch(g, ldg, packed_weight(w_f, 'conv', 'fwd', gy.dtype), gxf, ldgf, None, None, None, None, B, H, W, Cout, H, W, c1,
+                     1, 1, 1, 1, 0, 0, False, 1, 0, False)
+        # weight gradient, segment by segment
+        xsv, ldxs = aligned_view(xs)
+        xfv, ldxf = aligned_view(xf)
+        gw_s, _ = wgrad(xsv, ldxs, gpv, ldgp, weight.detach()[:, :c0], None, ConvSpec('conv', 1, 1, 1, 1, 0, 0, h, w))
+        gw_f, _ = wgrad(xfv, ldxf, g, ldg, weight.detach()[:, c0:], None, ConvSpec('conv', 1, 1, 1, 1, 0, 0, H, W))
+        gw = torch.cat([gw_s * float(k * k), gw_f], 1)
+        return gxs, gxf, gw, None, None
+
+
+def upcat_conv1x1(xs, xf, weight, act=0):
+    """act(conv1x1(cat([nearest_upsample(xs to xf's size), xf], 1))); None when the fused kernel does not apply (f32 parity
+    path, sizes that are not a power-of-two multiple): the caller then composes interpolate + concat + conv."""
+    if xs.dtype != torch.bfloat16 or xf.dtype != torch.bfloat16 or weight.dim() != 4 or weight.shape[2:] != (1, 1):
+        return None
+    H, W, h, w = xf.shape[2], xf.shape[3], xs.shape[2], xs.shape[3]
+    if h == 0 or H % h or W % w or H // h != W // w:
+        return None
+    k = H // h
+    if k < 1 or k & (k - 1) or k > 64 or xs.shape[1] % 8:
+        return None
+    return _UpCatConv1x1Fn.apply(xs, xf, weight, k.bit_length() - 1, act)
+
+
 def conv_same_geometry(H, W, k, stride, dil):
     """TF-'same' padding of conv2dSame (models/torch_model.py:276-281): output ceil(size/stride), extra pad bottom/right."""
     def one(size):

@@ -182,17 +182,15 @@ class TrainStep:
         except BaseException:
             pass
         del graph
-        # capture_begin put torch's default CUDA generator into capture mode and only a completed capture_end takes it
-        # out again ("Offset increment outside graph capture" on the next torch.randn(device='cuda')): a trivial
-        # capture that does complete resets it
+        # capture_begin put torch's default CUDA generator into capture mode and only a completed capture_end takes it out
+        # again ("Offset increment outside graph capture" on the next torch.randn(device='cuda')): give the generator a
+        # fresh, non-capturing state object with the same seed
         try:
-            torch.cuda.synchronize()
-            g2, scratch = torch.cuda.CUDAGraph(), torch.zeros(1, device=self.flat_p.device)
-            with torch.cuda.stream(cap):
-                g2.capture_begin()
-                scratch.add_(1)
-                g2.capture_end()
-            del g2
+            dev = self.flat_p.device
+            gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+            fresh = torch.Generator(device=dev)
+            fresh.manual_seed(gen.initial_seed())
+            gen.graphsafe_set_state(fresh.graphsafe_get_state())
         except BaseException as e:
             import sys
             sys.stderr.write("[TrainStep] could not reset the capture state of torch's CUDA generator: %s\n" % str(e).splitlines()[0])

@@ -13,14 +13,14 @@ def _rel(a, b):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,Cin,ldx,Cout,pro,groups,stats", [
-    (4, 32, 64, 64, 64, 128, True, 2, True),        # DenseNet conv1, first layer of a block
-    (4, 32, 64, 224, 256, 128, True, 2, True),      # channel prefix of a wider slab, partial last chunk
-    (2, 64, 128, 128, 128, 224, False, 1, False),   # data gradient of a bottleneck: two cout blocks
-    (8, 16, 32, 1024, 1024, 512, True, 2, False),   # transition
-    (2, 64, 96, 65, 72, 64, False, 1, False),       # odd channel count in a padded pixel stride
-    (2, 64, 96, 64, 64, 65, False, 1, False),       # odd output channels
-    (2, 48, 88, 32, 32, 33, False, 1, True),        # ragged last tile (pixels not a multiple of 128) + statistics
-    (16, 8, 16, 992, 1024, 128, True, 2, True)])    # deepest block: one tile per image
+    (16, 64, 64, 64, 64, 128, True, 2, True),       # DenseNet conv1, first layer of a block
+    (16, 64, 64, 224, 256, 128, True, 2, True),     # channel prefix of a wider slab, partial last chunk
+    (4, 64, 128, 128, 128, 224, False, 1, False),   # data gradient of a bottleneck: two cout blocks
+    (8, 64, 128, 1024, 1024, 512, True, 2, False),  # transition-like: 16 chunks, 4 cout blocks
+    (6, 64, 96, 65, 72, 64, False, 1, False),       # odd channel count in a padded pixel stride
+    (6, 64, 96, 64, 64, 65, False, 1, False),       # odd output channels
+    (8, 48, 88, 32, 32, 33, False, 1, True),        # ragged last tile (pixels not a multiple of 256) + statistics
+    (16, 8, 16, 992, 1024, 128, True, 2, True)])    # small map: stays on the halo-tile kernel (same contract)
 def test_gemm1x1_matches_f32_contraction(B, H, W, Cin, ldx, Cout, pro, groups, stats):
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
     torch.manual_seed(Cin * 7 + Cout)
@@ -77,3 +77,34 @@ def test_conv1x1_cat_matches_torch(B, H, W, c0, us0, c1, us1, Cout, act, bias):
     want = torch.relu(want) if act == 1 else (torch.sigmoid(want) if act == 2 else want)
     assert tuple(y.shape) == tuple(want.shape) and torch.isfinite(y.float()).all()
     assert _rel(y, want) < 6e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,h,w,us,c0,c1,Cout", [(2, 32, 64, 3, 64, 1, 64), (2, 64, 128, 2, 64, 1, 32), (2, 16, 32, 4, 32, 1, 32)])
+def test_upcat_conv1x1_forward_backward_match_torch(B, h, w, us, c0, c1, Cout):
+    """The fused upsample + concat + 1x1 + ReLU node (ops.upcat_conv1x1) against torch's interpolate / cat / conv2d / relu on
+    the same bf16-rounded operands: output, both input gradients and the weight gradient (whose two halves are computed
+    without ever forming the upsampled map)."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    torch.manual_seed(us * 100 + c0)
+    dev = torch.device("cuda:0")
+    H, W = h << us, w << us
+    xs0 = torch.randn(B, c0, h, w, device=dev).to(torch.bfloat16)
+    xf0 = torch.randn(B, c1, H, W, device=dev).to(torch.bfloat16)
+    w0 = (torch.randn(Cout, c0 + c1, 1, 1, device=dev) * (1.0 / (c0 + c1) ** 0.5))
+    gy = (torch.randn(B, Cout, H, W, device=dev) * 0.1).to(torch.bfloat16)
+    xs, _ = ops.alloc_nhwc(B, c0, h, w, torch.bfloat16, dev); xs.copy_(xs0); xs.requires_grad_(True)
+    xf, _ = ops.alloc_nhwc(B, c1, H, W, torch.bfloat16, dev); xf.copy_(xf0); xf.requires_grad_(True)
+    wt = w0.clone().requires_grad_(True)
+    ops.set_step_context(None)
+    y = ops.upcat_conv1x1(xs, xf, wt, act=1)
+    assert y is not None
+    y.backward(gy)
+    rs, rf = xs0.float().requires_grad_(True), xf0.float().requires_grad_(True)
+    rw = w0.to(torch.bfloat16).float().requires_grad_(True)
+    want = torch.relu(F.conv2d(torch.cat([F.interpolate(rs, scale_factor=1 << us, mode='nearest'), rf], 1), rw))
+    want.backward(gy.float() * (y.float() > 0))          # same ReLU mask as the bf16 output (values at the rounding edge)
+    assert _rel(y, want) < 6e-3
+    assert _rel(xs.grad, rs.grad) < 2e-2, _rel(xs.grad, rs.grad)
+    assert _rel(xf.grad, rf.grad) < 2e-2, _rel(xf.grad, rf.grad)
+    assert _rel(wt.grad, rw.grad) < 2e-2, _rel(wt.grad, rw.grad)

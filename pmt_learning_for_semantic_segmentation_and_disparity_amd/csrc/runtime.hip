@@ -74,6 +74,8 @@ extern "C" int sdhip_abort_capture(void* stream) {
   st = hipStreamCaptureStatusNone;
   e = hipStreamIsCapturing(s, &st);
   (void)hipGetLastError();
-  if (e != hipSuccess || st != hipStreamCaptureStatusNone) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "abort_capture: the stream is still capturing");
+  // ROCm 7.2 leaves an invalidated capture stream in the Invalidated state even after EndCapture; that stream is dropped by
+  // the caller and every other stream works again.  Only a stream that is still ACTIVELY capturing is an error.
+  if (e == hipSuccess && st == hipStreamCaptureStatusActive) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "abort_capture: the stream is still capturing");
   return was_open;
 }

@@ -182,6 +182,13 @@ class TrainStep:
         except BaseException:
             pass
         del graph
+
+    def _abandon_capture(self):
+        """A capture that raised recorded launches but executed none: device state (parameters, moments, running
+        statistics, dropout seed) is that of the last eager warm-up step.  Only host-side bookkeeping of the half-recorded
+        step has to be reset before eager steps continue."""
+        self.graph, self.use_graph, self.loss = None, False, None
+        torch.cuda.synchronize()               # raises if the process could not be brought back: nothing can run then
         # capture_begin put torch's default CUDA generator into capture mode and only a completed capture_end takes it out
         # again ("Offset increment outside graph capture" on the next torch.randn(device='cuda')): give the generator a
         # fresh, non-capturing state object with the same seed
@@ -194,13 +201,6 @@ class TrainStep:
         except BaseException as e:
             import sys
             sys.stderr.write("[TrainStep] could not reset the capture state of torch's CUDA generator: %s\n" % str(e).splitlines()[0])
-
-    def _abandon_capture(self):
-        """A capture that raised recorded launches but executed none: device state (parameters, moments, running
-        statistics, dropout seed) is that of the last eager warm-up step.  Only host-side bookkeeping of the half-recorded
-        step has to be reset before eager steps continue."""
-        self.graph, self.use_graph, self.loss = None, False, None
-        torch.cuda.synchronize()               # raises if the process could not be brought back: nothing can run then
         self.ctx.unpacks = []
         self.ctx.keep.clear()
         ops.invalidate_packed_weights()

@@ -171,7 +171,7 @@ def test_dropout_mask_is_shared_by_forward_and_backward():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("how", ["python_raise", "hip_invalidate"])
-def test_failed_capture_falls_back_to_a_consistent_eager_step(how):
+def test_failed_capture_falls_back_to_a_consistent_eager_step(how, capfd):
     """A hipGraph capture that raises leaves TrainStep usable: the steps that follow equal those of an eager-only run
     (the recording pass executed nothing, so parameters / moments / running statistics are those of the warm-up)."""
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
@@ -195,6 +195,9 @@ def test_failed_capture_falls_back_to_a_consistent_eager_step(how):
     assert abs(got[1] - want[3]) <= 2e-2 * max(1.0, abs(want[3])), (got, want)
     n5 = ts.model.resnet_features.resnet_features.norm5
     assert int(n5.num_batches_tracked) == 8      # 4 executed steps x 2 statistics groups; the recording pass counted nothing
+    err = capfd.readouterr().err
+    assert "continuing WITHOUT a graph" in err and "could not" not in err, err
+    torch.randn(8, device="cuda")                # torch's own CUDA generator is usable again (it was in capture mode)
 
 
 @pytest.mark.gpu

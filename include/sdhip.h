@@ -385,6 +385,16 @@ int sdhip_prepare_sample(const unsigned char* left, const unsigned char* right, 
                          const float* stdv, void* out_left, void* out_right, int ld_img, float* out_seg,
                          int ld_seg, int n_seg, float* out_disp, int dtype, void* stream);
 
+/* Horizontal flip of ONE prepared stereo sample, in place — RandomCrop(flipHorizontal=True) of
+ * util/utilTorchDataLoader.py:476-499 (cityscapes): the two images are swapped and mirrored; every pixel of the disparity
+ * and one-hot maps moves to column max(int(c - disp), 0) of its row (the largest source column wins a contested target,
+ * untouched targets keep their content), the last 10 / 20 columns are cleared, pixels without disparity go to the void
+ * channel (the last of n_seg), then both maps are mirrored.  left/right: H x W pixels of `dtype`, pixel stride ld_img;
+ * seg: f32 one-hot, pixel stride ld_seg; disp: dense f32.  workspace: sdhip_flip_sample_workspace_bytes(H, W, n_seg). */
+long sdhip_flip_sample_workspace_bytes(int H, int W, int n_seg);
+int sdhip_flip_sample(void* left, void* right, int ld_img, float* seg, int ld_seg, int n_seg, float* disp, int H, int W,
+                      void* workspace, long workspace_bytes, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

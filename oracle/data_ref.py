@@ -62,3 +62,27 @@ def prepare_sample(left, right, seg, depth, dataset, n_labels, max_d, activation
     norm = lambda a: ((cut(a) / 255.0 - normalize[0]) / normalize[1]).astype(np.float32)   # :247-248
     chw = lambda a: np.ascontiguousarray(a.transpose(2, 0, 1))
     return chw(norm(left)), chw(norm(right)), chw(cut(seg_image)), chw(cut(disp)[:, :, None].astype(np.float32))
+
+
+def flip_sample(left, right, seg, disp):
+    """RandomCrop's horizontal flip (util/utilTorchDataLoader.py:476-499) on CHW float arrays as prepare_sample returns them:
+    -> left, right, seg, disp flipped.  The scatter `a[r, target] = a[r, c]` is a fancy-index assignment evaluated in
+    row-major order: for contested targets the largest source column wins, untouched targets keep their content."""
+    C, H, W = seg.shape
+    d = disp[0].copy()
+    sg = seg.transpose(1, 2, 0).copy()
+    new_left, new_right = right[:, :, ::-1].copy(), left[:, :, ::-1].copy()
+    cols = np.arange(W)[None, :].repeat(H, 0)
+    tgt = (cols - d).astype(np.int64)          # float64 difference truncated towards zero
+    tgt[tgt < 0] = 0
+    d_new, s_new = d.copy(), sg.copy()
+    for r in range(H):
+        for c in range(W):                     # increasing c: later (larger) columns overwrite
+            d_new[r, tgt[r, c]] = d[r, c]
+            s_new[r, tgt[r, c], :] = sg[r, c, :]
+    d_new[:, -10:] = 0
+    s_new[:, -20:, :] = 0
+    mask = (d_new == 0).astype(np.float32)
+    s_new[:, :, -1] = mask
+    s_new[:, :, :-1] *= (1 - mask[:, :, None])
+    return new_left, new_right, np.ascontiguousarray(s_new[:, ::-1, :].transpose(2, 0, 1)), np.ascontiguousarray(d_new[None, :, ::-1])

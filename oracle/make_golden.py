@@ -386,8 +386,13 @@ def gen_data():
              ("roses_crop", "roses", 2, 192, "linear", (16, 24), True, ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))),
              ("roses_sigmoid_be", "roses", 2, 12, "sigmoid", (0, 0), False, ((0., 0., 0.), (1., 1., 1.))),
              ("garden_tanh", "garden", 9, 12, "tanh", (16, 32), True, ((0., 0., 0.), (1., 1., 1.))),
-             ("city_linear", "cityscapes", 19, 192, "linear", (16, 24), True, ((0., 0., 0.), (1., 1., 1.)))]
+             ("city_linear", "cityscapes", 19, 192, "linear", (16, 24), True, ((0., 0., 0.), (1., 1., 1.))),
+             ("city_flip", "cityscapes", 19, 192, "linear", (16, 32), True, ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))),
+             ("city_flip_whole", "cityscapes", 19, 192, "linear", (24, 40), True, ((0., 0., 0.), (1., 1., 1.)))]
+    if not hasattr(np, "int"):
+        np.int = int          # RandomCrop's flip uses the alias numpy removed in 1.24 (util/utilTorchDataLoader.py:485)
     for name, ds, n_labels, max_d, act, crop, little, norm in cases:
+        flip = name.startswith("city_flip")
         left = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         right = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         if ds == "roses":
@@ -409,20 +414,28 @@ def gen_data():
             dpath = p("d.pfm")
             arrays[name + ".depth_file"] = np.frombuffer(open(dpath, "rb").read(), dtype=np.uint8)
         else:
-            d16 = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+            d16 = rng.integers(0, 65536 if not flip else 256 * 9, (H, W), dtype=np.uint16)    # flip cases: disparities < 9 px
             d16[rng.uniform(size=(H, W)) < 0.2] = 0
             Image.fromarray(d16).save(p("d.png"))
             dpath = p("d.png")
             arrays[name + ".depth_u16"] = d16
         normalize = np.array(norm, dtype=np.float32)
         tf = DL.RandomCrop(list(crop), datasetName=ds, is_down=False, sliceandSwitch=False, augment_DoubleLeftImg=False,
-                           focusPerson=False, resizeImg=False, flipHorizontal=False)
+                           focusPerson=False, resizeImg=False, flipHorizontal=flip)
         dset = DL.CustomDataset([(p("l.png"), p("r.png"))], [(dpath, p("s.png"), p("i.png"))], n_labels, max_d, ds, normalize,
                                 output_activation=act, transform=tf, to_tensor=DL.ToTensor())
-        torch.manual_seed(123)
+        seed = 123
+        if flip:      # a seed whose draws (crop offsets, then the 50 % flip decision) end in "flip"
+            from pmt_learning_for_semantic_segmentation_and_disparity_amd import data as PD    # host-side draw helpers only (no GPU call)
+            for seed in range(123, 200):
+                torch.manual_seed(seed)
+                PD.draw_crop(H, W, list(crop), ds)
+                if PD.draw_flip(ds, True):
+                    break
+        torch.manual_seed(seed)
         s = dset[0]
         arrays.update(flat(name, dict(left_u8=left, right_u8=right, seg_u8=seg, n_labels=np.int64(n_labels), max_d=np.float64(max_d),
-                                      crop=np.array(crop, dtype=np.int64), normalize=normalize, seed=np.int64(123),
+                                      crop=np.array(crop, dtype=np.int64), normalize=normalize, seed=np.int64(seed), flip=np.int64(flip),
                                       left=s["left"].numpy(), right=s["right"].numpy(), seg=s["seg"].numpy().astype(np.float32),
                                       disp=s["disp"].numpy().astype(np.float32))))
         arrays[name + ".dataset"] = np.array(ds)

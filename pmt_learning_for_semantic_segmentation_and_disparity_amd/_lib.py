@@ -81,10 +81,13 @@ SIGNATURES = {
     "sdhip_step_metrics": [_p, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _l, _i, _f, _i, _i, _p],
     "sdhip_prepare_sample": [_p, _p, _l, _i, _p, _l, _i, _i, _i, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p, _p,
                              _p, _p, _i, _p, _i, _i, _p, _i, _p],
+    "sdhip_flip_sample": [_p, _p, _i, _p, _i, _i, _p, _i, _i, _p, _l, _i, _p],
     "sdhip_bn_bwd_apply_fin": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _d, _i, _i, _p],
 }
 _lib.sdhip_lovasz_workspace_bytes.argtypes = [_l, _i]
 _lib.sdhip_lovasz_workspace_bytes.restype = _l
+_lib.sdhip_flip_sample_workspace_bytes.argtypes = [_i, _i, _i]
+_lib.sdhip_flip_sample_workspace_bytes.restype = _l
 _lib.sdhip_conv_packed_elems.argtypes = [_i, _i, _i, _i]
 _lib.sdhip_conv_packed_elems.restype = _l
 for _name, _args in SIGNATURES.items():

@@ -122,3 +122,108 @@ extern "C" int sdhip_prepare_sample(const unsigned char* left, const unsigned ch
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }
+
+// ---- horizontal flip of a prepared stereo sample (RandomCrop(flipHorizontal=True), util/utilTorchDataLoader.py:476-499) ----
+// The reference, on the cropped HWC arrays (cityscapes only):
+//   left' = fliplr(right), right' = fliplr(left);
+//   every pixel (r, c) of disp and seg is moved to column max(int(c - disp[r,c]), 0) of the SAME arrays, in row-major
+//   order (a fancy-index assignment: where several pixels land on one column the LAST one, i.e. the largest c, wins;
+//   columns nobody lands on keep their old content);
+//   disp[:, -10:] = 0, seg[:, -20:] = 0; mask = (disp == 0); the void channel (last) = mask, all others *= 1 - mask;
+//   disp and seg are flipped left-right.
+// Three kernels per sample: the winner per (row, column) by atomicMax, the shifted / masked / flipped maps into scratch,
+// and the copy back together with the swap + flip of the two images.
+namespace {
+
+__global__ __launch_bounds__(256) void flip_init_kernel(int* __restrict__ winner, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) winner[i] = -1;
+}
+
+__global__ __launch_bounds__(256) void flip_winner_kernel(const float* __restrict__ disp, int* __restrict__ winner, int H, int W) {
+  const long n = (long)H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % W);
+    const long r = i / W;
+    int t = (int)((double)c - (double)disp[i]);      // numpy: int64 column minus float32 disparity = float64, .astype(int) truncates
+    t = t < 0 ? 0 : t;
+    if (t < W) atomicMax(winner + r * W + t, c);
+  }
+}
+
+__global__ __launch_bounds__(256) void flip_maps_kernel(const float* __restrict__ disp, const float* __restrict__ seg, int ld_seg, int n_seg,
+                                                        const int* __restrict__ winner, float* __restrict__ dtmp, float* __restrict__ stmp,
+                                                        int H, int W) {
+  const long n = (long)H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    const long r = i / W;
+    const int wsrc = winner[i];
+    const long src = wsrc >= 0 ? r * W + wsrc : i;
+    float d = disp[src];
+    if (x >= W - 10) d = 0.f;
+    const float mask = d == 0.f ? 1.f : 0.f;
+    const long dst = r * W + (W - 1 - x);            // the final left-right flip
+    dtmp[dst] = d;
+    for (int k = 0; k < n_seg; ++k) {
+      float v = x >= W - 20 ? 0.f : seg[src * ld_seg + k];
+      v = k == n_seg - 1 ? mask : v * (1.f - mask);
+      stmp[dst * n_seg + k] = v;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void flip_apply_kernel(T* __restrict__ left, T* __restrict__ right, int ld_img, float* __restrict__ disp,
+                                                         float* __restrict__ seg, int ld_seg, int n_seg, const float* __restrict__ dtmp,
+                                                         const float* __restrict__ stmp, int H, int W) {
+  const long n = (long)H * W;
+  const int half = (W + 1) / 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    const long r = i / W;
+    disp[i] = dtmp[i];
+    for (int k = 0; k < n_seg; ++k) seg[i * ld_seg + k] = stmp[i * n_seg + k];
+    if (x < half) {                                  // this thread owns the column pair (x, W-1-x) of both images
+      const long a = (r * W + x) * ld_img, b = (r * W + (W - 1 - x)) * ld_img;
+      for (int ch = 0; ch < 3; ++ch) {
+        const T la = left[a + ch], lb = left[b + ch], ra = right[a + ch], rb = right[b + ch];
+        left[a + ch] = rb; left[b + ch] = ra;
+        right[a + ch] = lb; right[b + ch] = la;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" long sdhip_flip_sample_workspace_bytes(int H, int W, int n_seg) {
+  if (H <= 0 || W <= 0 || n_seg <= 0) return 0;
+  return (long)H * W * 4 * (2 + n_seg);
+}
+
+extern "C" int sdhip_flip_sample(void* left, void* right, int ld_img, float* seg, int ld_seg, int n_seg, float* disp, int H, int W,
+                                 void* workspace, long workspace_bytes, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(left && right && seg && disp && workspace && H > 0 && W > 20 && n_seg >= 2 && ld_img >= 3 && ld_seg >= n_seg,
+                  "flip_sample: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "flip_sample: unknown dtype %d", dtype);
+  SDHIP_CHECK_ARG(workspace_bytes >= sdhip_flip_sample_workspace_bytes(H, W, n_seg), "flip_sample: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const long n = (long)H * W;
+  int* winner = (int*)workspace;
+  float* dtmp = (float*)workspace + n;
+  float* stmp = dtmp + n;
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(flip_init_kernel, dim3((unsigned)blocks), dim3(256), 0, s, winner, n);
+  hipLaunchKernelGGL(flip_winner_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)disp, winner, H, W);
+  hipLaunchKernelGGL(flip_maps_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)disp, (const float*)seg, ld_seg, n_seg,
+                     (const int*)winner, dtmp, stmp, H, W);
+  if (dtype == SDHIP_F32)
+    hipLaunchKernelGGL(flip_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float*)left, (float*)right, ld_img, disp, seg, ld_seg,
+                       n_seg, (const float*)dtmp, (const float*)stmp, H, W);
+  else
+    hipLaunchKernelGGL(flip_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)left, (bf16_t*)right, ld_img, disp, seg, ld_seg,
+                       n_seg, (const float*)dtmp, (const float*)stmp, H, W);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}

@@ -84,6 +84,16 @@ def draw_crop(h, w, output_size, dataset_name="roses", is_down=False):
     return top, left, new_h, new_w
 
 
+def draw_flip(dataset_name, flip_horizontal=True):
+    """The flip decision as RandomCrop draws it (util/utilTorchDataLoader.py:476): `flipHorizontal and multinomial([.5,.5])
+    and datasetName == 'cityscapes'` — the draw happens whenever the option is on (short-circuit order), after the crop
+    offsets of draw_crop; only cityscapes samples are actually flipped."""
+    if not flip_horizontal:
+        return False
+    hit = bool(torch.multinomial(torch.tensor([0.5, 0.5]), 1).item())
+    return hit and dataset_name == "cityscapes"
+
+
 class SamplePreparer:
     """Fills batch tensors sample by sample on the GPU.
 
@@ -173,6 +183,18 @@ class SamplePreparer:
              self.seg_mode, 128, ptr(self.lut), ptr(dd), pitch, self.depth_mode, big, H, W, top, lft, oh, ow, self.fb, self.max_d,
              self.activation, ctypes.cast(self.mean, ctypes.c_void_p), ctypes.cast(self.std, ctypes.c_void_p), ptr(ol), ptr(orr),
              ld_img, ptr(os_), ld_seg, self.n_seg, ptr(od), _lib.dtype_code(bl), stream_ptr())
+
+    def flip_slot(self, batch, b):
+        """Horizontal flip of slot `b` in place (RandomCrop(flipHorizontal=True), util/utilTorchDataLoader.py:476-499): call it
+        after prepare_into when data.draw_flip said so.  Asynchronous."""
+        bl, br, bs, bd = batch
+        H, W = bl.shape[2], bl.shape[3]
+        nbytes = _lib._lib.sdhip_flip_sample_workspace_bytes(H, W, self.n_seg)
+        ws = getattr(self, "_flip_ws", None)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._flip_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        call("sdhip_flip_sample", ptr(bl[b]), ptr(br[b]), bl.stride(3), ptr(bs[b]), bs.stride(3), self.n_seg, ptr(bd[b]), H, W,
+             ptr(ws), ws.numel(), _lib.dtype_code(bl), stream_ptr())
 
     def release(self):
         """Drop the staged uint8 inputs (call after the batch has been consumed or the stream synchronised)."""

@@ -496,9 +496,11 @@ class dsnet(nn.Module):
         y = self._match(a, b)
         y1 = up(self.Conv2DownUp3(x1), size=y.shape[2:], mode='bilinear')
         y = self.Conv2DownUp4(ops.concat([y1, y]))
-        y2 = up(y, scale_factor=8)
-        xl2 = up(xl2, size=y2.shape[2:], mode='bilinear')
-        d = self.dispoutConv(self.Conv2DownUp5(self.conv1d_2[0].run(ops.concat([y2, xl2]), act=1)))
+        xl2 = up(xl2, size=(8 * y.shape[2], 8 * y.shape[3]), mode='bilinear')
+        d0 = ops.upcat_conv1x1(y, xl2, self.conv1d_2[0].c2d.weight, act=1)
+        if d0 is None:
+            d0 = self.conv1d_2[0].run(ops.concat([up(y, scale_factor=8), xl2]), act=1)
+        d = self.dispoutConv(self.Conv2DownUp5(d0))
         disp = up(d, size=size, mode='bilinear')
         x = up(x, scale_factor=4)
         y3 = up(y, scale_factor=2)
@@ -510,7 +512,10 @@ class dsnet(nn.Module):
         x = up(x, size=a[0].shape[2:], mode='bilinear')
         x = self.conv2DT_BA2[0].fused(self.conv1d_5[0].run(ops.concat([x, a[0]]), act=1), act=1)
         xl1 = up(xl1, size=x.shape[2:], mode='bilinear')
-        s2 = self.branchConv(self.Conv2DownUp7(self.conv1d_6[0].run(ops.concat([x, xl1]), act=1)))
+        s0 = ops.upcat_conv1x1(x, xl1, self.conv1d_6[0].c2d.weight, act=1)
+        if s0 is None:
+            s0 = self.conv1d_6[0].run(ops.concat([x, xl1]), act=1)
+        s2 = self.branchConv(self.Conv2DownUp7(s0))
         s2 = up(ops.log_softmax(s2), size=size, mode='bilinear')
         seg2 = ops.axpby(0.9, s2, 0.1, seg1)
         y4 = self.conv1d_9[0].run(ops.concat([a[6], b[6]]), act=1)
@@ -520,9 +525,11 @@ class dsnet(nn.Module):
         y5 = self.Conv2DownUp8(x3)
         y = up(y, size=y5.shape[2:], mode='bilinear')
         y = self.Conv2DownUp9(ops.concat([y5, y]))
-        y = up(y, scale_factor=2)
-        xl3 = up(xl3, size=y.shape[2:], mode='bilinear')
-        d2 = self.Conv2DownUp10[1](self.Conv2DownUp10[0](self.conv1d_8[0].run(ops.concat([y, xl3]), act=1)))
+        xl3 = up(xl3, size=(2 * y.shape[2], 2 * y.shape[3]), mode='bilinear')
+        e0 = ops.upcat_conv1x1(y, xl3, self.conv1d_8[0].c2d.weight, act=1)
+        if e0 is None:
+            e0 = self.conv1d_8[0].run(ops.concat([up(y, scale_factor=2), xl3]), act=1)
+        d2 = self.Conv2DownUp10[1](self.Conv2DownUp10[0](e0))
         d2 = up(d2, size=size, mode='bilinear')
         return seg1, disp, seg2, ops.axpby(0.8, d2, 0.2, disp)
 

@@ -126,6 +126,18 @@ int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                      int D, int Do, int kd, int sd, int pad_d,
                      int in_relu, int groups, int act, int accumulate,
                      int dtype, void* stream);
+
+/* One sub-pixel phase of nn.ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1) (models_psmnet/stackhourglass.py:25-29;
+ * 2-D: D = kd = 1): output voxel 2m + off of an axis receives input m with kernel tap 1 when off = 0, and inputs m, m+1
+ * with taps 2, 0 when off = 1 — so each of the 8 phases (off_d, off_h, off_w) is a stride-1 correlation with a
+ * (1+off_d) x (1+off_h) x (1+off_w) sub-kernel over the UN-stuffed input, 27 taps in all instead of 8 x 27 over a
+ * zero-stuffed volume.  x: [B][D][H][W][Cin]; y: the [B][2D][2H][2W][Cout] output volume (pixel stride ldy), of which this
+ * call writes the voxels (2d + off_d, 2h + off_h, 2w + off_w); wpacked: the phase's sub-kernel packed [kd][q][t][m][c]
+ * with taps ordered input-offset-major (sdhip_conv_pack_weights per depth tap); stats: as sdhip_conv2d_fwd (the eight
+ * calls add into the same sums).  bf16 / f32, 16-byte aligned pixels. */
+int sdhip_conv2d_fwd_phase(const void* x, const void* wpacked, void* y, double* stats, int stats_ld, int stats_nrep,
+                           int B, int H, int W, int Cin, int ldx, int Cout, int ldy, int kh, int kw,
+                           int D, int kd, int groups, int off_d, int off_h, int off_w, int dtype, void* stream);
 /* prezeroed != 0: the caller already zeroed dw_packed / dbias (one arena memset per step instead of one per call).
  * dW (packed f32, zeroed here) = sum over pixels of dy (x) pro(x); dbias[m] = sum dy (optional). */
 int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* dbias,

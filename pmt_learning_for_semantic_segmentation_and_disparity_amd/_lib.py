@@ -40,6 +40,7 @@ SIGNATURES = {
     "sdhip_conv_pack_weights": [_p, _p, _i, _i, _i, _l, _l, _i, _i, _p],
     "sdhip_conv_unpack_wgrad": [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p],
     "sdhip_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 27 + [_p],
+    "sdhip_conv2d_fwd_phase": [_p, _p, _p, _p, _i, _i] + [_i] * 16 + [_p],
     "sdhip_conv2d_wgrad": [_p, _p, _p, _p, _p, _p] + [_i] * 24 + [_p],
     "sdhip_conv1x1_cat_fwd": [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_conv_pack_batch": [_p, _i, _i, _p],

@@ -31,6 +31,9 @@ struct FastArgs {
   int tiles_w, ntg;                    // tiles per output row, tap groups per chunk
   int tg, stats_ld, nrep, tail, dma;   // tail: Cin % (elements per 16 bytes) != 0 -> mask the last chunk; dma: halo by LDS-DMA
   long rep_stride;
+  // interleaved output (one sub-pixel phase of a stride-2 transposed convolution): output voxel (dz, oh, ow) of image b is
+  // stored at (dz*omul + ooz, oh*omul + ooy, ow*omul + oox) of a volume omul times as large per axis.  omul = 1: plain.
+  int omul, ooz, ooy, oox;
 };
 
 // source of every padding / dead lane of an LDS-DMA load
@@ -429,16 +432,19 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
 
-  T* const yb = (T*)p.y + (long)blockIdx.z * p.Ho * p.Wo * p.ldy;
+  const int om = p.omul;
+  const int WoD = p.Wo * om;                                                   // row pitch (pixels) of the stored image
+  const long zimg = om == 1 ? (long)blockIdx.z : ((long)b * p.Do + dz) * om + p.ooz;
+  T* const yb = (T*)p.y + zimg * (p.Ho * om) * WoD * p.ldy + ((long)p.ooy * WoD + p.oox) * p.ldy;
   // (accumulating launches take the general path: its per-tile branches keep the old values' loads from being hoisted
   //  together, which would cost ~100 VGPRs — a wave of occupancy — in every launch of this kernel)
   const bool interior = oh0 + TH <= p.Ho && ow0 + TW <= p.Wo && n0 + BN <= p.Cout && !p.accumulate;   // wave-uniform
   if (interior) {
-    T* const d0 = yb + ((long)(oh0 + pt0 / TWT) * p.Wo + ow0 + (pt0 % TWT) * 16 + l15) * p.ldy + n0 + 4 * lg;
+    T* const d0 = yb + ((long)(oh0 + pt0 / TWT) * om * WoD + (ow0 + (pt0 % TWT) * 16 + l15) * om) * p.ldy + n0 + 4 * lg;
 #pragma unroll
     for (int ni = 0; ni < NT_PIX; ++ni) {
       const int pt = pt0 + ni;
-      T* dst = d0 + (long)(((pt / TWT) - (pt0 / TWT)) * p.Wo + ((pt % TWT) - (pt0 % TWT)) * 16) * p.ldy;   // uniform offset
+      T* dst = d0 + (long)(((pt / TWT) - (pt0 / TWT)) * om * WoD + ((pt % TWT) - (pt0 % TWT)) * 16 * om) * p.ldy;   // uniform offset
 #pragma unroll
       for (int mi = 0; mi < NT_CO; ++mi) {
         f32x4 v = acc[mi][ni];
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
       const int pt = pt0 + ni;
       const int oh = oh0 + pt / TWT, ow = ow0 + (pt % TWT) * 16 + l15;
       const bool valid = oh < p.Ho && ow < p.Wo;
-      T* dst = yb + ((long)oh * p.Wo + ow) * p.ldy;
+      T* dst = yb + ((long)oh * om * WoD + (long)ow * om) * p.ldy;
 #pragma unroll
       for (int mi = 0; mi < NT_CO; ++mi) {
         const int co = n0 + mi * 16 + 4 * lg;

@@ -417,15 +417,15 @@ size_t halo_bytes_of(const ConvGeom& g, int th, int tw, int per_tap) {
 
 }  // namespace
 
-extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
-                                const float* bias, const float* in_scale, const float* in_shift,
-                                double* stats, int stats_ld, int stats_nrep,
-                                int B, int H, int W, int Cin, int ldx,
-                                int Ho, int Wo, int Cout, int ldy,
-                                int kh, int kw, int stride, int dil, int pad_t, int pad_l,
-                                int D, int Do, int kd, int sd, int pad_d,
-                                int in_relu, int groups, int act, int accumulate,
-                                int dtype, void* stream) {
+static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
+                           const float* bias, const float* in_scale, const float* in_shift,
+                           double* stats, int stats_ld, int stats_nrep,
+                           int B, int H, int W, int Cin, int ldx,
+                           int Ho, int Wo, int Cout, int ldy,
+                           int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                           int D, int Do, int kd, int sd, int pad_d,
+                           int in_relu, int groups, int act, int accumulate,
+                           int dtype, void* stream, int omul, int ooz, int ooy, int oox) {
   SDHIP_CHECK_ARG(x && wpacked && y, "conv2d_fwd: null pointer");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv2d_fwd: unknown dtype %d", dtype);
   SDHIP_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_fwd: empty tensor");
@@ -473,7 +473,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
   hipStream_t s = (hipStream_t)stream;
   const int per_tap_any = (kh > 1 || kw > 1) && dil >= 4 && kd == 1;
   // ---- thin path (conv_thin.h): <= 8 input channels -> 1 output channel on the vector ALUs ----
-  if (Cout == 1 && Cin <= V && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale &&
+  if (omul == 1 && Cout == 1 && Cin <= V && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale &&
       !accumulate && kh * kw <= kThinMaxT && Ho == H + 2 * pad_t - dil * (kh - 1) && Wo == W + 2 * pad_l - dil * (kw - 1) &&
       pad_t >= 0 && pad_l >= 0 && !dg.conv_no_thin) {
     ThinArgs t;
@@ -488,7 +488,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
     return SDHIP_OK;
   }
   // ---- 1x1 as a streaming GEMM (conv_gemm.h): bf16, plain stride-1 1x1 over whole images ----
-  if (dtype == SDHIP_BF16 && kh == 1 && kw == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && D == 1 && Do == 1 &&
+  if (omul == 1 && dtype == SDHIP_BF16 && kh == 1 && kw == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && D == 1 && Do == 1 &&
       Ho == H && Wo == W && !accumulate && !dg.conv_generic && !dg.conv_no_gemm) {
     GemmArgs g;
     g.seg[0] = GemmSeg{x, ldx, Cin, 0};
@@ -512,6 +512,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
     f.Cin = Cin; f.ldx = ldx; f.Cout = Cout; f.Mpad = a.Mpad; f.ldy = ldy;
     f.in_relu = in_relu; f.bpg = B / groups; f.act = act; f.accumulate = accumulate;
     f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride; f.tail = (Cin % V) != 0;
+    f.omul = omul; f.ooz = ooz; f.ooy = ooy; f.oox = oox;
     f.dma = !in_scale && !f.tail;
     bool fbig = big;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -543,6 +544,7 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
       return dtype == SDHIP_BF16 ? launch_fast_any<bf16_t>(f, fbig, ks, bn, lds, s) : launch_fast_any<float>(f, fbig, ks, bn, lds, s);
     }
   }
+  if (omul != 1) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_phase: interleaved output needs the aligned fast path (ldx %% 8, ldy %% 4)");
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int th = big ? 8 : 4, tw = big ? 32 : 16;
     const int per_tap = per_tap_any;   // halo would be >= 4x the tile in each direction's holes
@@ -588,4 +590,28 @@ extern "C" int sdhip_conv1x1_cat_fwd(const void* x0, int ld0, int c0, int us0, c
   g.stats_ld = Cout; g.nrep = 1; g.rep_stride = 0;
   if (!gemm1x1_ok(g, 1, true)) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv1x1_cat_fwd: operands not 16-byte aligned / grid not divisible by the upsampling factor");
   return launch_gemm_any(g, (hipStream_t)stream);
+}
+
+
+extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
+                                const float* bias, const float* in_scale, const float* in_shift,
+                                double* stats, int stats_ld, int stats_nrep,
+                                int B, int H, int W, int Cin, int ldx,
+                                int Ho, int Wo, int Cout, int ldy,
+                                int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                                int D, int Do, int kd, int sd, int pad_d,
+                                int in_relu, int groups, int act, int accumulate,
+                                int dtype, void* stream) {
+  return conv2d_fwd_impl(x, wpacked, y, bias, in_scale, in_shift, stats, stats_ld, stats_nrep, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy,
+                         kh, kw, stride, dil, pad_t, pad_l, D, Do, kd, sd, pad_d, in_relu, groups, act, accumulate, dtype, stream, 1, 0, 0, 0);
+}
+
+// One sub-pixel phase of a stride-2 transposed convolution (see include/sdhip.h): a stride-1 correlation whose outputs are
+// written to every second voxel of a volume twice as large in each of depth / height / width.
+extern "C" int sdhip_conv2d_fwd_phase(const void* x, const void* wpacked, void* y, double* stats, int stats_ld, int stats_nrep,
+                                      int B, int H, int W, int Cin, int ldx, int Cout, int ldy, int kh, int kw,
+                                      int D, int kd, int groups, int off_d, int off_h, int off_w, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(off_d >= 0 && off_d < 2 && off_h >= 0 && off_h < 2 && off_w >= 0 && off_w < 2, "conv2d_fwd_phase: phase offsets are 0 or 1");
+  return conv2d_fwd_impl(x, wpacked, y, nullptr, nullptr, nullptr, stats, stats_ld, stats_nrep, B, H, W, Cin, ldx, H, W, Cout, ldy,
+                         kh, kw, 1, 1, 0, 0, D, D, kd, 1, 0, 0, groups, 0, 0, dtype, stream, 2, off_d, off_h, off_w);
 }

@@ -1324,14 +1324,119 @@ class _StuffFn(torch.autograd.Function):
         return gx, None, None, None
 
 
+# Sub-pixel decomposition of ConvTranspose3d(k=3, s=2, p=1, output_padding=1): per axis, output 2m takes input m with tap 1;
+# output 2m+1 takes inputs m, m+1 with taps 2, 0.  Phase (pd, ph, pw) is a stride-1 correlation with a (1+pd)x(1+ph)x(1+pw)
+# sub-kernel; the 27 taps, ordered phase by phase (input offset major), index the flat 3x3x3 kernel as follows.
+_PHASE_TAPS = ([1], [2, 0])
+_PHASES = [(pd, ph, pw) for pd in (0, 1) for ph in (0, 1) for pw in (0, 1)]
+_PHASE_INDEX = [a * 9 + b * 3 + c for (pd, ph, pw) in _PHASES for a in _PHASE_TAPS[pd] for b in _PHASE_TAPS[ph] for c in _PHASE_TAPS[pw]]
+_phase_index_dev = {}
+
+
+def _phase_packs(weight, dtype):
+    """The eight packed sub-kernels of a (Cin, Cout, 3, 3, 3) ConvTranspose3d weight: one gather reorders the 27 taps phase by
+    phase into a (Cout, Cin, 27) buffer, from which every (phase, depth tap) is packed with its own strides."""
+    Cin, Cout = weight.shape[0], weight.shape[1]
+    dev = weight.device
+    idx = _phase_index_dev.get(str(dev))
+    if idx is None:
+        idx = _phase_index_dev[str(dev)] = torch.tensor(_PHASE_INDEX, dtype=torch.int64, device=dev)
+    wre = weight.detach().reshape(Cin, Cout, 27).index_select(2, idx).transpose(0, 1).contiguous()      # (Cout, Cin, 27)
+    dt = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+    packs, off = [], 0
+    for (pd, ph, pw) in _PHASES:
+        nd, T = 1 + pd, (1 + ph) * (1 + pw)
+        per = _lib.packed_elems(Cout, Cin, T, dt)
+        buf = torch.empty(per * nd, dtype=dtype, device=dev)
+        es = buf.element_size()
+        for kdi in range(nd):
+            call("sdhip_conv_pack_weights", ctypes_ptr(wre.data_ptr() + 4 * (off + kdi * T)), ctypes_ptr(buf.data_ptr() + es * per * kdi),
+                 Cout, Cin, T, Cin * 27, 27, 0, dt, stream_ptr())
+        packs.append(buf)
+        off += nd * T
+    return packs, wre
+
+
+class _Deconv3dS2BNActFn(torch.autograd.Function):
+    """y = act(BatchNorm3d(ConvTranspose3d(k=3, s=2, p=1, op=1)(x))) (+ residual), models_psmnet/stackhourglass.py:25-29,42-48.
+    Forward: eight sub-pixel phases over the un-stuffed volume (27 taps per input voxel, not 8 x 27 over a zero-stuffed
+    one), their statistics summed by the conv epilogues.  Backward: the adjoint of a transposed convolution is the
+    stride-2 convolution with the same weight, so the data gradient is a strided forward convolution of dy and the weight
+    gradient the strided weight-gradient kernel with the roles of x and dy exchanged — no stuffing either."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, D, bn, act, groups):
+        _require_gpu(x, weight)
+        Bimg, Cin, H, W = x.shape
+        Btrue = Bimg // D
+        Cout = weight.shape[1]
+        xv, ldx = aligned_view(x)
+        Bo = Btrue * 2 * D
+        yraw, ldr_ = alloc_nhwc(Bo, Cout, 2 * H, 2 * W, x.dtype, x.device)
+        train = bn.training
+        ws = _zeros((NREP, groups, 2, Cout), torch.float64, x.device)[0] if train else None
+        packs, keep = _phase_packs(weight, x.dtype)
+        for (pd, ph, pw), wp in zip(_PHASES, packs):
+            call("sdhip_conv2d_fwd_phase", ptr(xv), ptr(wp), ptr(yraw), ptr(ws), ws.stride(-2) if ws is not None else 0, NREP if ws is not None else 1,
+                 Btrue, H, W, Cin, ldx, Cout, ldr_, 1 + ph, 1 + pw, D, 1 + pd, groups, pd, ph, pw, dtype_code(x), stream_ptr())
+        count = (Bo // groups) * 4 * H * W
+        rv, ldr = nhwc_view(residual) if residual is not None else (None, 0)
+        y, ldy = alloc_nhwc(Bo, Cout, 2 * H, 2 * W, x.dtype, x.device)
+        if train and _fused_bn():
+            scale, shift, mean, invstd = [torch.empty((groups, Cout), dtype=torch.float32, device=x.device) for _ in range(4)]
+            _bn_track(bn, groups)
+            call("sdhip_affine_act_bn", ptr(yraw), ldr_, ptr(y), ldy, ptr(rv), ldr, ptr(ws), ws.stride(-2), NREP, ptr(bn.weight),
+                 ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                 Bo * 4 * H * W, Cout, groups, float(count), float(bn.eps), float(0.1 if bn.momentum is None else bn.momentum),
+                 act, dtype_code(x), stream_ptr())
+        else:
+            scale, shift, mean, invstd = _bn_finalize(ws, NREP, bn, count, groups)
+            call("sdhip_affine_act", ptr(yraw), ldr_, ptr(y), ldy, ptr(rv), ldr, ptr(scale), ptr(shift), Bo * 4 * H * W,
+                 Cout, groups, act, dtype_code(x), stream_ptr())
+        ctx.cfg = (D, act, groups, ldx, ldr_, count, train, residual is not None)
+        ctx.save_for_backward(xv, weight, gamma, beta, yraw, scale, shift, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xv, weight, gamma, beta, yraw, scale, shift, mean, invstd = ctx.saved_tensors
+        D, act, groups, ldx, ldraw, count, train, has_res = ctx.cfg
+        Bimg, Cin, H, W = xv.shape
+        Btrue = Bimg // D
+        Bo, Cout = yraw.shape[0], yraw.shape[1]
+        Ho, Wo = 2 * H, 2 * W
+        npix = Bo * Ho * Wo
+        dt = dtype_code(xv)
+        g, ldg = nhwc_view(gy)
+        graw, ldgr = alloc_nhwc(Bo, Cout, Ho, Wo, xv.dtype, xv.device)
+        if train and act in (0, 1, 2) and _fused_bn():
+            dgamma, dbeta = bn_backward_two_phase(g, ldg, yraw, ldraw, graw, ldgr, scale, shift, mean, invstd, gamma, beta, npix,
+                                                  Cout, groups, act, count, dt)
+        elif train and act in (0, 1, 2):
+            dgamma, dbeta, dS = _bn_backward(g, ldg, yraw, ldraw, None, 0, scale, shift, mean, invstd, gamma, npix, Cout,
+                                             groups, act, count, True, dt, beta=beta)
+            call("sdhip_bn_bwd_apply", ptr(g), ldg, ptr(yraw), ldraw, ptr(graw), ldgr, ptr(scale), ptr(shift), ptr(dS), Cout,
+                 npix, Cout, groups, act, dt, stream_ptr())
+        else:
+            dgamma, dbeta, dS = _bn_backward(g, ldg, yraw, ldraw, graw, ldgr, scale, shift, mean, invstd, gamma, npix, Cout,
+                                             groups, act, count, train, dt, beta=beta)
+        # adjoint of the transposed convolution: Conv3d(weight viewed as (out = Cin, in = Cout), stride 2, padding 1) of graw
+        spec = ConvSpec('conv', 3, 3, 2, 1, 1, 1, H, W, 2 * D, D, 3, 2, 1)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx, ldgx = alloc_nhwc(Bimg, Cin, H, W, xv.dtype, xv.device)
+            _conv_launch(graw, ldgr, packed_weight(weight, 'conv', 'fwd', xv.dtype), gx, ldgx, None, None, None, None, Btrue, Ho, Wo, Cout,
+                         H, W, Cin, 3, 3, 2, 1, 1, 1, False, 1, 0, False, 1, spec.depth())
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw, _ = wgrad(graw, ldgr, xv, ldx, weight, None, spec)       # "input" = dy, "output gradient" = x: same (Cin, Cout, 3,3,3) layout
+        return gx, gw, dgamma, dbeta, (gy if has_res else None), None, None, None, None
+
+
 def deconv3d_s2_bn_act(x, D, weight, bn, act=0, residual=None, groups=1):
     """nn.ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1) + BatchNorm3d (models_psmnet/stackhourglass.py:25-29):
-    a stride-1 correlation with flipped taps over the zero-stuffed volume; output extent exactly 2x."""
-    Bimg, C, H, W = x.shape
-    xs = _StuffFn.apply(x, D, 2, 2)
-    Ds, Hs, Ws = 2 * D - 1, 2 * H - 1, 2 * W - 1
-    spec = ConvSpec('deconv', 3, 3, 1, 1, 1, 1, 2 * H, 2 * W, Ds, 2 * D, 3, 1, 1)
-    return _ConvBNActFn.apply(xs, weight, bn.weight, bn.bias, residual, spec, bn, act, groups), 2 * D
+    output extent exactly 2x; sub-pixel phases forward, strided convolution kernels backward (_Deconv3dS2BNActFn)."""
+    return _Deconv3dS2BNActFn.apply(x, weight, bn.weight, bn.bias, residual, D, bn, act, groups), 2 * D
 
 
 class _CostVolumeFn(torch.autograd.Function):

@@ -1,8 +1,11 @@
-"""Turn gpurun_out/roofline/* (tools/roofline_profile.sh) into the committed profiles/r01_roofline_* files."""
-import csv, json, os, re, sys
+"""Turn gpurun_out/roofline/* (tools/roofline_profile.sh) into the committed profiles/r02_* files."""
+import collections, csv, json, os, re, shutil
 R = "gpurun_out/roofline"
+TAG = "r02"
 os.makedirs("profiles", exist_ok=True)
-def kstats(path, out, top=25):
+
+
+def kstats(path, out, top=40):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     with open(out, "w") as f:
@@ -10,22 +13,64 @@ def kstats(path, out, top=25):
         for r in rows[:top]:
             f.write('"%s",%s,%s,%s,%s\n' % (r["Name"][:140], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
     return rows
-rows = kstats(R + "/stats/r_kernel_stats.csv", "profiles/r01_roofline_kernel_stats.csv")
-kstats(R + "/step/r_kernel_stats.csv", "profiles/r01_bench_graph_kernel_stats.csv", 40)
+
+
+def counters(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    return re.sub(r"^void ", "", n).split("(")[0][:80]
+
+
+rows = kstats(R + "/stats/r_kernel_stats.csv", "profiles/%s_roofline_kernel_stats.csv" % TAG)
+kstats(R + "/step/r_kernel_stats.csv", "profiles/%s_bench_graph_kernel_stats.csv" % TAG, 60)
+shutil.copy(R + "/step_summary.txt", "profiles/%s_step_summary.txt" % TAG)
 conv = [r for r in rows if "conv_fast_kernel" in r["Name"]][0]
-def pmc(path, name):
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Counter_Name"] == name and "conv_fast_kernel" in r["Kernel_Name"]]
-    return sum(v) / len(v), len(v)
-fetch, nf = pmc(R + "/fetch/r_counter_collection.csv", "FETCH_SIZE")
-write, nw = pmc(R + "/write/r_counter_collection.csv", "WRITE_SIZE")
+avg = lambda acc, pat, name: (lambda v: (sum(v) / len(v), len(v)))([x for k, d in acc.items() if pat in k for x in d.get(name, [])])
+fetch, nf = avg(counters(R + "/fetch/r_counter_collection.csv"), "conv_fast_kernel", "FETCH_SIZE")
+write, nw = avg(counters(R + "/write/r_counter_collection.csv"), "conv_fast_kernel", "WRITE_SIZE")
+m1 = counters(R + "/mfma/r_counter_collection.csv")
+busy, _ = avg(m1, "conv_fast_kernel", "SQ_VALU_MFMA_BUSY_CYCLES")
+sqbusy, _ = avg(m1, "conv_fast_kernel", "SQ_BUSY_CYCLES")
 line = [l for l in open(R + "/stats.log") if l.startswith("{")][-1]
 roof = json.loads(line)["roofline"]
 # FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950 -> x2
 hbm = 2.0 * fetch * 1024 + write * 1024
+dur_cycles = float(conv["AverageNs"]) * 2.4            # 2.4 GHz shader clock
+# SQ_VALU_MFMA_BUSY_CYCLES sums, over the chip's 1024 SIMDs, the cycles a SIMD's matrix pipe was busy
+mfma_frac = busy / (dur_cycles * 1024.0)
 out = {"kernel": conv["Name"][:160], "avg_ns_rocprof": float(conv["AverageNs"]), "calls": int(conv["Calls"]),
        "ms_per_launch_bench": roof["ms_per_launch"], "achieved_tflops_bench": roof["achieved"],
        "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write, "launches_fetch": nf, "launches_write": nw,
        "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 2 * 8 * 256 * 512 * 64 * 2 + 64 * 64 * 25 * 2,
-       "note": "hbm = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes, bench.py --roofline-only"}
-json.dump(out, open("profiles/r01_roofline_traffic.json", "w"), indent=1)
+       "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": busy, "SQ_BUSY_CYCLES_per_launch": sqbusy, "mfma_busy_frac": round(mfma_frac, 4),
+       "note": "hbm = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes, bench.py --roofline-only; mfma_busy_frac = "
+               "SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles at 2.4 GHz x 1024 SIMDs)"}
+json.dump(out, open("profiles/%s_roofline_traffic.json" % TAG, "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+# per-kernel-family table of one eager step: duration (kernel trace of the graph run), MFMA busy, HBM bytes
+sm = counters(R + "/step_mfma/r_counter_collection.csv")
+sf = counters(R + "/step_fetch/r_counter_collection.csv")
+sw = counters(R + "/step_write/r_counter_collection.csv")
+fam = collections.defaultdict(lambda: dict(n=0, busy=0.0, sq=0.0, fetch=0.0, write=0.0))
+for k, d in sm.items():
+    f = fam[short(k)]
+    f["n"] += len(d.get("SQ_BUSY_CYCLES", [])); f["busy"] += sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", [])); f["sq"] += sum(d.get("SQ_BUSY_CYCLES", []))
+for k, d in sf.items():
+    fam[short(k)]["fetch"] += sum(d.get("FETCH_SIZE", []))
+for k, d in sw.items():
+    fam[short(k)]["write"] += sum(d.get("WRITE_SIZE", []))
+dur = {}
+for r in csv.DictReader(open(R + "/step_mfma/r_counter_collection.csv")):
+    pass
+with open("profiles/%s_step_counters.csv" % TAG, "w") as f:
+    f.write("kernel,launches (3 eager steps),SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES,hbm_MB (2*FETCH+WRITE)\n")
+    for k, v in sorted(fam.items(), key=lambda kv: -(2 * kv[1]["fetch"] + kv[1]["write"])):
+        f.write('"%s",%d,%.4g,%.4g,%.1f\n' % (k, v["n"], v["busy"], v["sq"], (2 * v["fetch"] + v["write"]) * 1024 / 1e6))
+print(open("profiles/%s_step_counters.csv" % TAG).read()[:3000])

@@ -4,7 +4,7 @@
 #   2. rocprofv3 --pmc FETCH_SIZE        -> HBM read bytes   (separate pass; x2 on gfx950, MI355X_MICROARCH.md §HBM)
 #   3. rocprofv3 --pmc WRITE_SIZE        -> HBM write bytes  (separate pass)
 # plus the kernel statistics of one whole bench run.  Outputs under gpurun_out/roofline/; tools/roofline_collect.py
-# turns them into profiles/r01_roofline_* (committed).
+# turns them into profiles/r02_* (committed).
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/roofline
@@ -12,5 +12,14 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python bench.py --roofline-only > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o r -- python bench.py --roofline-only > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o r -- python bench.py --roofline-only > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step -o r -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/step.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/mfma -o r -- python bench.py --roofline-only > $OUT/mfma.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/mfma2 -o r -- python bench.py --roofline-only > $OUT/mfma2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step -o r -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > $OUT/step.log 2>&1
+python tools/trace_summary.py $OUT/step/r_kernel_trace.csv > $OUT/step_summary.txt
+# MFMA-busy of the kernels of a whole (eager) step: conv_fast / wgrad_fast families
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/step_mfma -o r -- python bench.py --steps 1 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --no-secondary > $OUT/step_mfma.log 2>&1
+# HBM bytes of the BatchNorm elementwise kernels of a whole (eager) step
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/step_fetch -o r -- python bench.py --steps 1 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --no-secondary > $OUT/step_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/step_write -o r -- python bench.py --steps 1 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --no-secondary > $OUT/step_write.log 2>&1
+python tools/roofline_collect.py
 tail -1 $OUT/stats.log

@@ -189,6 +189,15 @@ int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, int nrep, co
                           const float* mean, const float* invstd,
                           float* dgamma, float* dbeta, double* dstats, int stats_ld, int accumulate_flags /* bit0: dstats +=, bit1: dgamma/dbeta += */,
                           int C, int groups, double count, int train, void* stream);
+/* sdhip_bn_finalize_bwd (train mode, dstats accumulated) of a BatchNorm over the first Cf channels of a DenseNet slab fused
+ * with sdhip_stats_fix of the 32 slab channels [cs, cs + 32) that the next layer of the backward walk needs:
+ * gout = gin + dS[g][0][c] + 2 x dS[g][1][c] with dS INCLUDING this call's contribution for those channels (which is not
+ * written back: nothing reads it again).  dscale/dshift: replicas [nrep][groups][Cf] of sdhip_affine_act_bwd;
+ * accumulate_params: dgamma/dbeta += (flat gradient buffer) instead of =.  Rows 16-byte aligned. */
+int sdhip_stats_fix_fin(const void* gin, int ldgi, const void* x, int ldx, void* gout, int ldgo, long npix,
+                        double* dS, int ldc, int cs, const float* dscale, const float* dshift, int nrep,
+                        const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                        int accumulate_params, int Cf, int groups, double count, int dtype, void* stream);
 /* y = act(x*scale[g][c] + shift[g][c]) (+ res). scale/shift may be NULL (identity). */
 int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const void* res, int ldr,
                      const float* scale, const float* shift, long npix, int C, int groups, int act,
@@ -201,6 +210,14 @@ int sdhip_affine_act_bwd(const void* gy, int ldg, const void* x, int ldx, void* 
                          long npix, int C, int groups, int act, int accumulate, int prezeroed, int dtype, void* stream);
 /* out[row][c] += sum_r ws[r][row][c] over the 2*groups statistics rows (folds conv-epilogue replicas into a slab). */
 int sdhip_stats_replica_sum(const double* ws, double* out, int nrep, int groups, int C, int ldw, int ldo, void* stream);
+/* sdhip_stats_replica_sum of the Cn newest channels (replicas ws[nrep][groups][2][ldw]) into the statistics slab
+ * S[groups][2][ldc] at channel c_new0, followed by sdhip_bn_finalize of the first C >= c_new0 + Cn channels from S — one
+ * launch instead of two on the DenseNet's layer-to-layer chain (models/densenet.py:41-45: norm1 of layer l+1 reads every
+ * channel up to layer l's output). */
+int sdhip_bn_fold_finalize(const double* ws, int nrep, int ldw, int c_new0, int Cn, double* S, int ldc,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           float* scale, float* shift, float* mean_out, float* invstd_out, int C, int groups,
+                           double count, float eps, float momentum, void* stream);
 /* gout = gin + dstats[g][0][c] + 2*x*dstats[g][1][c]: the gradient that flows through the batch statistics. */
 int sdhip_stats_fix(const void* gin, int ldgi, const void* x, int ldx, void* gout, int ldgo,
                     const double* dstats, int stats_ld, long npix, int C, int groups, int dtype, void* stream);

@@ -52,7 +52,9 @@ SIGNATURES = {
     "sdhip_dropout_channels": [_p, _i, _p, _i, _p, _l, _i, _i, _i, _f, _i, _p],
     "sdhip_channel_stats": [_p, _i, _p, _i, _i, _l, _i, _i, _i, _i, _p],
     "sdhip_stats_replica_sum": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "sdhip_bn_fold_finalize": [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _d, _f, _f, _p],
     "sdhip_bn_finalize": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _d, _f, _f, _p],
+    "sdhip_stats_fix_fin": [_p, _i, _p, _i, _p, _i, _l, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _d, _i, _p],
     "sdhip_bn_finalize_bwd": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _i, _p],
     "sdhip_affine_act": [_p, _i, _p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _i, _p],
     "sdhip_affine_act_bwd": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _l, _i, _i, _i, _i, _i, _i, _p],

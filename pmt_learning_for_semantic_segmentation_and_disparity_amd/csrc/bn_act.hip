@@ -592,6 +592,61 @@ __global__ void replica_sum_kernel(const double* __restrict__ ws, double* __rest
   out[(long)row * ldo + c] += s;
 }
 
+// fold + finalize in one launch (DenseNet: the statistics of a layer's 32 new slab channels are folded into the slab
+// statistics and the NEXT layer's norm1 — which reads all channels up to and including the new ones — is finalized):
+// channel c of [c_new0, c_new0 + Cn) first adds its replica sums into S, then every channel < C is finalized from S.
+__global__ void bn_fold_finalize_kernel(const double* __restrict__ ws, int nrep, int ldw, int c_new0, int Cn, double* __restrict__ S, int ldc,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                                        float* __restrict__ rvar, float* __restrict__ scale, float* __restrict__ shift,
+                                        float* __restrict__ mean_out, float* __restrict__ invstd_out, int C, int G, double count, float eps,
+                                        float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float gm = gamma[c], bt = beta[c];
+  float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+  const bool fresh = c >= c_new0 && c < c_new0 + Cn;
+  for (int g = 0; g < G; ++g) {
+    double s1 = S[((long)g * 2 + 0) * ldc + c], s2 = S[((long)g * 2 + 1) * ldc + c];
+    if (fresh) {
+      const int cn = c - c_new0;
+#pragma unroll 8
+      for (int r = 0; r < nrep; ++r) {
+        const double* Sr = ws + (long)r * G * 2 * ldw;
+        s1 += Sr[((long)g * 2 + 0) * ldw + cn];
+        s2 += Sr[((long)g * 2 + 1) * ldw + cn];
+      }
+      S[((long)g * 2 + 0) * ldc + c] = s1;
+      S[((long)g * 2 + 1) * ldc + c] = s2;
+    }
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    if (var < 0.) var = 0.;
+    const float inv = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gm * inv;
+    scale[g * C + c] = sc;
+    shift[g * C + c] = (float)((double)bt - mu * (double)sc);
+    mean_out[g * C + c] = (float)mu;
+    invstd_out[g * C + c] = inv;
+    const double unb = count > 1. ? var * count / (count - 1.) : var;
+    rm = (1.f - momentum) * rm + momentum * (float)mu;
+    rv = (1.f - momentum) * rv + momentum * (float)unb;
+  }
+  if (rmean) { rmean[c] = rm; rvar[c] = rv; }
+}
+
+extern "C" int sdhip_bn_fold_finalize(const double* ws, int nrep, int ldw, int c_new0, int Cn, double* S, int ldc,
+                                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                      float* scale, float* shift, float* mean_out, float* invstd_out, int C, int groups,
+                                      double count, float eps, float momentum, void* stream) {
+  SDHIP_CHECK_ARG(ws && S && gamma && beta && scale && shift && mean_out && invstd_out && nrep >= 1 && Cn > 0 && c_new0 >= 0 &&
+                  c_new0 + Cn <= C && ldw >= Cn && ldc >= C && groups >= 1 && count > 0., "bn_fold_finalize: bad arguments");
+  SDHIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_fold_finalize: running statistics must come together");
+  hipLaunchKernelGGL(bn_fold_finalize_kernel, dim3(sdhip_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, ws, nrep, ldw, c_new0, Cn, S, ldc,
+                     gamma, beta, running_mean, running_var, scale, shift, mean_out, invstd_out, C, groups, count, eps, momentum);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
 extern "C" int sdhip_stats_replica_sum(const double* ws, double* out, int nrep, int groups, int C, int ldw, int ldo, void* stream) {
   SDHIP_CHECK_ARG(ws && out && nrep >= 1 && groups >= 1 && C > 0 && ldw >= C && ldo >= C, "stats_replica_sum: bad arguments");
   const int rows = 2 * groups;
@@ -806,6 +861,131 @@ extern "C" int sdhip_bn_finalize(const double* stats, int ldc, int nrep, const f
   SDHIP_CHECK_ARG(!stats || (mean_out && invstd_out && count >= 1.), "bn_finalize: train mode needs mean/invstd outputs and a count");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(sdhip_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, ldc > 0 ? ldc : C, nrep > 0 ? nrep : 1, gamma, beta,
                      running_mean, running_var, scale, shift, mean_out, invstd_out, C, groups, count, eps, momentum);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+// bn_finalize_bwd of one DenseNet layer's norm1 + stats_fix of the NEXT layer to be processed, in one launch.
+// The backward walk of a dense block (models/densenet.py:41-45) alternates a per-channel kernel (the statistics gradient
+// dS of the slab channels a layer read) with an elementwise one (dy = g + dS0 + 2 x dS1 on the 32 channels the previous
+// layer wrote, which needs exactly the top 32 of the dS just updated).  Here every workgroup re-derives the 32 coefficients
+// it needs from the replica sums (a few KB from L2) while the first ceil(Cf/32) workgroups also do the per-channel work for
+// all Cf channels (dgamma, dbeta, dS of the channels below the slice — the slice's own dS is consumed here and never again).
+template <typename T>
+__global__ __launch_bounds__(256) void stats_fix_fin_kernel(const T* gin, int ldgi, const T* __restrict__ x, int ldx, T* gout, int ldgo,
+                                                            long npix_g, RowGeom rg, double* __restrict__ dS, int ldc, int cs,
+                                                            const float* __restrict__ dscale, const float* __restrict__ dshift, int nrep,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int acc_par, int Cf, int G, double inv_count) {
+  constexpr int N = Unit<T, true>::N;
+  __shared__ float red[2][8][32];
+  __shared__ float fa[32], fb[32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int nfb = (Cf + 31) >> 5;
+  if (blockIdx.z == 0 && blockIdx.y == 0 && (int)blockIdx.x < nfb) {     // workgroup-uniform: per-channel work of block blockIdx.x
+    const int c = blockIdx.x * 32 + cl;
+    const bool okc = c < Cf;
+    float dg = 0.f, db = 0.f;
+    for (int g = 0; g < G; ++g) {
+      float ds = 0.f, dh = 0.f;
+      if (okc) {
+#pragma unroll 4
+        for (int r = rl; r < nrep; r += 8) { ds += dscale[((long)r * G + g) * Cf + c]; dh += dshift[((long)r * G + g) * Cf + c]; }
+      }
+      __syncthreads();
+      red[0][rl][cl] = ds; red[1][rl][cl] = dh;
+      __syncthreads();
+      if (rl == 0 && okc) {
+        ds = 0.f; dh = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { ds += red[0][r][cl]; dh += red[1][r][cl]; }
+        const float gm = gamma[c];
+        const float mu = mean[g * Cf + c], inv = invstd[g * Cf + c];
+        const float t = ds - mu * dh;
+        dg += inv * t;
+        db += dh;
+        if (c < cs || c >= cs + 32) {                 // the slice's dS is formed (and consumed) by the elementwise part below
+          const double dinv = (double)gm * t;
+          const double dvar = -0.5 * dinv * (double)inv * inv * inv;
+          const double dmu = -(double)gm * inv * dh - 2.0 * mu * dvar;
+          dS[((long)g * 2 + 0) * ldc + c] += dmu * inv_count;
+          dS[((long)g * 2 + 1) * ldc + c] += dvar * inv_count;
+        }
+      }
+    }
+    if (rl == 0 && okc) {
+      dgamma[c] = acc_par ? dgamma[c] + dg : dg;
+      dbeta[c] = acc_par ? dbeta[c] + db : db;
+    }
+  }
+  // coefficients of the slice channels cs .. cs+31 for this workgroup's statistics group
+  const int g = blockIdx.z;
+  {
+    const int c = cs + cl;
+    float ds = 0.f, dh = 0.f;
+#pragma unroll 4
+    for (int r = rl; r < nrep; r += 8) { ds += dscale[((long)r * G + g) * Cf + c]; dh += dshift[((long)r * G + g) * Cf + c]; }
+    __syncthreads();
+    red[0][rl][cl] = ds; red[1][rl][cl] = dh;
+    __syncthreads();
+    if (rl == 0) {
+      ds = 0.f; dh = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { ds += red[0][r][cl]; dh += red[1][r][cl]; }
+      const float gm = gamma[c];
+      const float mu = mean[g * Cf + c], inv = invstd[g * Cf + c];
+      const float t = ds - mu * dh;
+      const double dinv = (double)gm * t;
+      const double dvar = -0.5 * dinv * (double)inv * inv * inv;
+      const double dmu = -(double)gm * inv * dh - 2.0 * mu * dvar;
+      fa[cl] = (float)(dS[((long)g * 2 + 0) * ldc + c] + dmu * inv_count);
+      fb[cl] = (float)(2.0 * (dS[((long)g * 2 + 1) * ldc + c] + dvar * inv_count));
+    }
+    __syncthreads();
+  }
+  ROW_TXTY(rg, tx, ty);
+  const int u = blockIdx.y * rg.tx + tx;
+  if (ty >= rg.ty || u >= rg.units) return;
+  const int c0 = u * N;
+  float a[N], b2[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { a[e] = fa[c0 + e]; b2[e] = fb[c0 + e]; }
+  const long base = (long)g * npix_g;
+  for (long pix = (long)blockIdx.x * rg.ty + ty; pix < npix_g; pix += (long)gridDim.x * rg.ty) {
+    float gv[N], xv[N];
+    Unit<T, true>::load(gin + (base + pix) * ldgi + c0, gv);
+    Unit<T, true>::load(x + (base + pix) * ldx + c0, xv);
+#pragma unroll
+    for (int e = 0; e < N; ++e) gv[e] = gv[e] + fmaf(xv[e], b2[e], a[e]);
+    Unit<T, true>::store(gout + (base + pix) * ldgo + c0, gv);
+  }
+}
+
+extern "C" int sdhip_stats_fix_fin(const void* gin, int ldgi, const void* x, int ldx, void* gout, int ldgo, long npix,
+                                   double* dS, int ldc, int cs, const float* dscale, const float* dshift, int nrep,
+                                   const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                   int accumulate_params, int Cf, int groups, double count, int dtype, void* stream) {
+  const int G = groups;
+  if (int rc = check_rows("stats_fix_fin", npix, 32, G, dtype)) return rc;
+  SDHIP_CHECK_ARG(gin && x && gout && dS && dscale && dshift && gamma && mean && invstd && dgamma && dbeta && ldgi >= 32 && ldx >= 32 &&
+                  ldgo >= 32 && cs >= 0 && cs + 32 <= Cf && ldc >= Cf && nrep >= 1 && count > 0., "stats_fix_fin: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int nfb = sdhip_cdiv(Cf, 32);
+#define ARGS(T) (const T*)gin, ldgi, (const T*)x, ldx, (T*)gout, ldgo, npix / G, pl.rg, dS, ldc, cs, dscale, dshift, nrep, gamma, mean, invstd, \
+                dgamma, dbeta, accumulate_params, Cf, G, 1.0 / count
+  if (dtype == SDHIP_F32) {
+    SDHIP_CHECK_ARG((vec_rows<float>(32, {ldgi, ldx, ldgo}, {gin, x, gout})), "stats_fix_fin: rows must be 16-byte aligned");
+    Plan pl = plan(32 / 4, npix / G, G);
+    if ((int)pl.grid.x < nfb) pl.grid.x = nfb;            // enough workgroups for the per-channel part
+    hipLaunchKernelGGL((stats_fix_fin_kernel<float>), pl.grid, dim3(256), 0, s, ARGS(float));
+  } else {
+    SDHIP_CHECK_ARG((vec_rows<bf16_t>(32, {ldgi, ldx, ldgo}, {gin, x, gout})), "stats_fix_fin: rows must be 16-byte aligned");
+    Plan pl = plan(32 / 8, npix / G, G);
+    if ((int)pl.grid.x < nfb) pl.grid.x = nfb;
+    hipLaunchKernelGGL((stats_fix_fin_kernel<bf16_t>), pl.grid, dim3(256), 0, s, ARGS(bf16_t));
+  }
+#undef ARGS
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }

@@ -42,6 +42,19 @@ def _fold(ws, S_slice, groups, C, Ct):
     call("sdhip_stats_replica_sum", ptr(ws), ptr(S_slice), nrep, groups, C, C, Ct, stream_ptr())
 
 
+def _fold_finalize(ws, c_new0, Cn, S, Ct, bn, C, count, groups):
+    """sdhip_bn_fold_finalize: (scale, shift, mean, invstd) of `bn` over the first C slab channels, folding the replicas `ws`
+    of the Cn newest channels (at c_new0) into the slab statistics S on the way (single GPU: no exchange in between)."""
+    dev = bn.weight.device
+    out = [torch.empty((groups, C), dtype=torch.float32, device=dev) for _ in range(4)]
+    ops._bn_track(bn, groups)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    call("sdhip_bn_fold_finalize", ptr(ws), NREP, ws.stride(-2), c_new0, Cn, ptr(S), Ct, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+         ptr(bn.running_var), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, groups, float((count)), float(bn.eps), float(mom),
+         stream_ptr())
+    return out
+
+
 def _wgrad(x, ldx, dy, lddy, weight, B, H, W, Cin, Cout, k, pad, in_scale, in_shift, groups, dt):
     """dW of a stride-1 nn.Conv2d (weight (Cout,Cin,k,k)) whose input is relu(prologue(x)); x is a (B,Cin,H,W) view."""
     spec = ops.ConvSpec('conv', k, k, 1, 1, pad, pad, H, W)
@@ -74,9 +87,16 @@ class _DenseBlockFn(torch.autograd.Function):
             call("sdhip_channel_stats", ptr(slab), Ct, ptr(ws0), C0, NREP, npix, C0, groups, 1, dt, stream_ptr())
             _fold(ws0, S[:, :, :C0], groups, C0, Ct)
         saved = []
+        pending = None      # (replicas of the previous layer's new channels, their channel offset): folded by the next finalize
+        fuse = training and ops.parallel.world_size() == 1
         for li, layer in enumerate(layers):
             Cin = C0 + li * growth
-            sc1, sh1, mu1, iv1 = _finalize(S[:, :, :Cin], 1, layer.norm1, count, groups, training, synced=True)
+            if pending is not None:
+                # ONE launch: fold the previous layer's statistics into the slab AND finalize this layer's norm1
+                sc1, sh1, mu1, iv1 = _fold_finalize(pending[0], pending[1], growth, S, Ct, layer.norm1, Cin, count, groups)
+                pending = None
+            else:
+                sc1, sh1, mu1, iv1 = _finalize(S[:, :, :Cin], 1, layer.norm1, count, groups, training, synced=True)
             w1 = ops.packed_weight(layer.conv1.weight, 'conv', 'fwd', dtype)
             y1 = ops.empty_nhwc(B, mid, H, W, dtype, dev)
             S2 = ops._zeros((NREP, groups, 2, mid), torch.float64, dev)[0] if training else None
@@ -88,7 +108,10 @@ class _DenseBlockFn(torch.autograd.Function):
             ops._conv_launch(y1, mid, w2, slab[:, Cin:Cin + growth], Ct, None, sc2, sh2, S3, B, H, W, mid, H, W, growth,
                              3, 3, 1, 1, 1, 1, True, groups, 0, False, NREP)
             if training:   # fold the replicas into this layer's slice of the slab statistics
-                _fold(S3, S[:, :, Cin:Cin + growth], groups, growth, Ct)
+                if fuse and li + 1 < L:
+                    pending = (S3, Cin)          # ... together with the next layer's norm1 finalize
+                else:
+                    _fold(S3, S[:, :, Cin:Cin + growth], groups, growth, Ct)
             saved.append((y1, sc1, sh1, mu1, iv1, sc2, sh2, mu2, iv2))
         ctx.block, ctx.groups, ctx.saved, ctx.slab = block, groups, saved, slab
         ctx.geom = (B, C0, H, W, growth, mid, Ct, training, count)
@@ -109,6 +132,8 @@ class _DenseBlockFn(torch.autograd.Function):
         call("sdhip_affine_act", ptr(gv), ldg, ptr(g_slab), Ct, None, 0, None, None, npix, Ct, 1, 0, dt, st)
         dS = gS_in.clone() if gS_in is not None else torch.zeros((groups, 2, Ct), dtype=torch.float64, device=dev)
         grads = []
+        fuse = training and growth == 32 and ops.parallel.world_size() == 1
+        pend = None    # norm1 backward sums of the layer processed last, finalized together with this layer's stats_fix
         for li in range(len(layers) - 1, -1, -1):
             layer = layers[li]
             y1, sc1, sh1, mu1, iv1, sc2, sh2, mu2, iv2 = ctx.saved[li]
@@ -117,8 +142,15 @@ class _DenseBlockFn(torch.autograd.Function):
             sl_x = slab[:, Cin:Cin + growth]
             # (1) total gradient of this layer's 32 output channels (all consumers are already accumulated)
             dy2 = ops.empty_nhwc(B, growth, H, W, dtype, dev)
-            call("sdhip_stats_fix", ptr(sl_g), Ct, ptr(sl_x), Ct, ptr(dy2), growth, ptr(dS[:, :, Cin:Cin + growth]), Ct,
-                 npix, growth, groups, dt, st)   # dS is all zero in eval mode
+            if pend is not None:
+                # ... in the same launch as the per-channel finalize of the layer above (sdhip_stats_fix_fin)
+                dsc, dsh, nl, dgam, dbet, direct, Cf = pend
+                call("sdhip_stats_fix_fin", ptr(sl_g), Ct, ptr(sl_x), Ct, ptr(dy2), growth, npix, ptr(dS), Ct, Cin, ptr(dsc), ptr(dsh), NREP,
+                     ptr(nl[0]), ptr(nl[1]), ptr(nl[2]), ptr(dgam), ptr(dbet), int(direct), Cf, groups, float(count), dt, st)
+                pend = None
+            else:
+                call("sdhip_stats_fix", ptr(sl_g), Ct, ptr(sl_x), Ct, ptr(dy2), growth, ptr(dS[:, :, Cin:Cin + growth]), Ct,
+                     npix, growth, groups, dt, st)   # dS is all zero in eval mode
             # (2) conv2 (3x3): data gradient w.r.t. relu(norm2(y1)), weight gradient
             wd2 = ops.packed_weight(layer.conv2.weight, 'conv', 'dgrad', dtype)
             gp2 = ops.empty_nhwc(B, mid, H, W, dtype, dev)
@@ -141,9 +173,21 @@ class _DenseBlockFn(torch.autograd.Function):
                              False, 1, 0, False)
             gw1 = _wgrad(slab, Ct, gp2, mid, layer.conv1.weight, B, H, W, Cin, mid, 1, 0, sc1, sh1, groups, dt)
             # (7) through relu + norm1's affine, accumulated into the slab gradient; (8) norm1's statistics -> dS
-            dg1, db1, _ = ops._bn_backward(gp1, Cin, slab, Ct, g_slab, Ct, sc1, sh1, mu1, iv1, layer.norm1.weight, npix, Cin,
-                                           groups, 1, count, training, dt, accumulate_gx=True, dstats=dS[:, :, :Cin],
-                                           accumulate_dstats=True, beta=layer.norm1.bias)
+            if fuse and li > 0:
+                # reductions now; the per-channel finalize rides on the next layer's stats_fix launch
+                both, pz = ops._zeros((2, NREP, groups, Cin), torch.float32, dev)
+                call("sdhip_affine_act_bwd", ptr(gp1), Cin, ptr(slab), Ct, ptr(g_slab), Ct, ptr(sc1), ptr(sh1), ptr(both[0]), ptr(both[1]),
+                     NREP, npix, Cin, groups, 1, 1, int(pz), dt, st)
+                tg, tb = ops._grad_target(layer.norm1.weight), ops._grad_target(layer.norm1.bias)
+                direct = tg is not None and tb is not None
+                dgam = tg if direct else torch.empty(Cin, dtype=torch.float32, device=dev)
+                dbet = tb if direct else torch.empty(Cin, dtype=torch.float32, device=dev)
+                pend = (both[0], both[1], (layer.norm1.weight, mu1, iv1), dgam, dbet, direct, Cin)
+                dg1, db1 = (None, None) if direct else (dgam, dbet)
+            else:
+                dg1, db1, _ = ops._bn_backward(gp1, Cin, slab, Ct, g_slab, Ct, sc1, sh1, mu1, iv1, layer.norm1.weight, npix, Cin,
+                                               groups, 1, count, training, dt, accumulate_gx=True, dstats=dS[:, :, :Cin],
+                                               accumulate_dstats=True, beta=layer.norm1.bias)
             grads.append((dg1, db1, gw1, dg2, db2, gw2))
         gx0 = ops.empty_nhwc(B, C0, H, W, dtype, dev)
         call("sdhip_stats_fix", ptr(g_slab), Ct, ptr(slab), Ct, ptr(gx0), C0, ptr(dS), Ct, npix, C0, groups, dt, st)

@@ -255,3 +255,66 @@ def test_bench_two_rank_launch_rehearsal():
     j = rows[0]
     assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["world_size"] == 2
     assert j["config"]["global_batch"] == 4 and j["value"] > 0 and j["scaling"] == "weak"
+
+
+def _vol_model_and_data():
+    """A PSMNet-style 3-D block: Conv3d(s1) + BN3d + ReLU -> Conv3d(s2) + BN3d + ReLU -> ConvTranspose3d(s2) + BN3d (+ skip)."""
+    import torch.nn as nn
+    from oracle.detweights import fill_state_dict, randn_input
+    blk = nn.ModuleDict(dict(c1=nn.Conv3d(16, 16, 3, padding=1, bias=False), b1=nn.BatchNorm3d(16),
+                             c2=nn.Conv3d(16, 32, 3, stride=2, padding=1, bias=False), b2=nn.BatchNorm3d(32),
+                             d3=nn.ConvTranspose3d(32, 16, 3, padding=1, output_padding=1, stride=2, bias=False), b3=nn.BatchNorm3d(16)))
+    blk = fill_state_dict(blk, 71).cuda().train()
+    return blk, randn_input(71, "vx", (4, 16, 4, 8, 16)), randn_input(72, "vg", (4, 16, 4, 8, 16))
+
+
+def _vol_forward(blk, xs):
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    B, C, D, H, W = xs.shape
+    x = xs.permute(0, 2, 3, 4, 1).reshape(B * D, H, W, C).permute(0, 3, 1, 2)     # (B*D, C, H, W) NHWC images
+    a, D1 = ops.conv3d_bn_act(x, D, blk["c1"].weight, blk["b1"], 1, 1, act=1)
+    b, D2 = ops.conv3d_bn_act(a, D1, blk["c2"].weight, blk["b2"], 2, 1, act=1)
+    y, D3 = ops.deconv3d_s2_bn_act(b, D2, blk["d3"].weight, blk["b3"], act=0, residual=a)
+    return y, D3
+
+
+def _gpu_vol_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import parallel
+    parallel.configure(dist.group.WORLD, world)
+    blk, x, g = _vol_model_and_data()
+    xs = x[rank * 2:(rank + 1) * 2].cuda().requires_grad_(True)
+    y, D3 = _vol_forward(blk, xs)
+    gs = g[rank * 2:(rank + 1) * 2].cuda()
+    y.backward(gs.permute(0, 2, 3, 4, 1).reshape(2 * D3, 8, 16, 16).permute(0, 3, 1, 2))
+    torch.cuda.synchronize()
+    q.put((rank, y.detach().float().cpu().numpy(), xs.grad.cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in blk.named_parameters()},
+           blk["b3"].running_var.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_gpu_sync_bn3d_two_ranks_equal_one_rank():
+    """BatchNorm3d under the 2-rank exchange (PSMNet's 3-D stack, models_psmnet/submodule.py:16-19, stackhourglass.py:25-48):
+    stride-1 / stride-2 Conv3d + BN3d + ReLU and the sub-pixel ConvTranspose3d + BN3d + skip, 2 ranks x 2 volumes vs 1 rank x 4."""
+    import numpy as np
+    res = _spawn2(_gpu_vol_worker, 29500 + (os.getpid() % 400))
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import parallel
+    parallel.configure(None, 1)
+    blk, x, g = _vol_model_and_data()
+    xs = x.cuda().requires_grad_(True)
+    y, D3 = _vol_forward(blk, xs)
+    y.backward(g.cuda().permute(0, 2, 3, 4, 1).reshape(4 * D3, 8, 16, 16).permute(0, 3, 1, 2))
+    yr, gx = y.detach().float().cpu().numpy(), xs.grad.cpu().numpy()
+    per = yr.shape[0] // 2
+    for r in res:
+        assert np.abs(r[1] - yr[r[0] * per:(r[0] + 1) * per]).max() <= 2e-5 * np.abs(yr).max()
+        assert np.abs(r[2] - gx[r[0] * 2:r[0] * 2 + 2]).max() <= 2e-5 * np.abs(gx).max()
+        np.testing.assert_allclose(r[4], blk["b3"].running_var.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    for k, p in blk.named_parameters():
+        gs = p.grad.cpu().numpy()
+        ga = res[0][3][k] + res[1][3][k]
+        assert np.linalg.norm(ga - gs) <= 2e-5 * max(np.linalg.norm(gs), 1e-20), k

@@ -217,3 +217,22 @@ def test_conv2downup_dropout_training():
     blk.eval()
     ye = blk(x)
     assert 0.3 < float((ye == 0).float().mean()) < 0.7
+
+
+@pytest.mark.gpu
+def test_graph_with_side_stream_matches_eager():
+    """The data-parallel configuration of the capture on one GPU: weight gradients on a second captured stream (forked and
+    joined inside the graph, as TrainStep does when world_size > 1), warm-up and capture on one stream.  Replays must equal
+    the eager steps of the same state."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    batch = synthetic_batch(2, 256, 256)
+    ref = TrainStep(_model(), dtype=torch.float32, use_graph=False, lr=1e-4)
+    want = [float(ref(*batch)) for _ in range(4)]
+    ops.set_step_context(None)
+    ts = TrainStep(_model(), dtype=torch.float32, use_graph=True, lr=1e-4, use_side_stream=True)
+    got = [float(ts(*batch)) for _ in range(2)]          # steps 3 and 4 (two warm-up steps inside the first call)
+    ops.set_step_context(None)
+    assert ts.use_graph and ts.graph is not None and ts.ctx.side is not None
+    assert abs(got[0] - want[2]) <= 2e-3 * max(1.0, abs(want[2])), (got, want)
+    assert abs(got[1] - want[3]) <= 2e-2 * max(1.0, abs(want[3])), (got, want)

@@ -1,0 +1,438 @@
+// Persistent K x K convolution for the full-resolution 5x5 layers (Conv2DownUp, models/blocks.py of the reference; the
+// ten launches that lead the training step's profile): bf16, stride 1, no dilation, <= 64 input and output channels.
+//
+// What the tap-group pipeline of conv_fast.h cannot do inside its 80 KiB (two workgroups per CU): keep more than one tap
+// of 64x64 weights per stage next to a 64-channel halo tile — 25 stages of 32 MFMAs per wave, a barrier and a DMA drain
+// between each.  This kernel owns the whole CU instead (one 512-thread workgroup, ~144 KiB of LDS) and is persistent:
+//
+//   tile    16 x 32 output pixels x all output channels; wave w computes pixel rows 2w, 2w+1 (4 MFMA pixel tiles) times
+//           BN output channels, exactly the register tile of conv_fast.h
+//   chunk   (tile, 32-channel half of the input): its halo image, (16+K-1) x 40 rows of 64 bytes, is 50 KiB, so TWO fit:
+//           the halo of chunk c+1 streams in by LDS-DMA, a couple of rounds per stage, while chunk c is computed
+//   stage   one kernel ROW of a chunk: K taps x BN rows of 64 bytes of weights (20 KiB), double-buffered; K * 4 * BN/16
+//           MFMAs per wave between two barriers (80 for 5x5 / 64 channels, against 32)
+//
+// Every fragment address is  buffer + wave row + compile-time constant + one of K per-lane registers:  with the halo
+// row pitch (40) and the 16-pixel column step multiples of 8 rows, the swizzle key of a pixel depends on
+// (kw + lane) only, so the inner loop carries no address arithmetic at all.
+//
+// LDS-DMA bookkeeping (the DMA is inline asm, invisible to the compiler's wait-count pass): the weights of the next
+// stage are issued first after a barrier, the halo rounds of the next chunk after them; `s_waitcnt vmcnt(n)` with
+// n = the halo instructions issued since then waits for exactly the weights.  The epilogue's global stores are drained
+// by the vmcnt(0) that opens the next chunk (loads and stores may retire out of order against each other, so no
+// counted wait ever has a store behind it).
+#pragma once
+#include <type_traits>
+#include "conv_fast.h"
+
+namespace {
+
+struct BandArgs {
+  const void* x; const void* wp; void* y;
+  const float* bias; double* stats;
+  int B, H, W, Ho, Wo, pad_t, pad_l;
+  int Cin, ldx, Cout, Mpad, ldy;
+  int bpg, act, stats_ld, nrep;
+  long rep_stride;
+  int tiles_w, tiles_hw, ntiles, tpw;      // tiles per output row / per image / in total / per workgroup
+  unsigned magic_hw, magic_tw;             // div_magic(tiles_hw), div_magic(tiles_w)
+  int dbg;                                 // diagnostic bits (SDHIP_TUNE_BAND_DBG): 1 no halo prefetch, 2 no weight DMA, 4 no MFMA, 8 no stores
+};
+
+template <int I, int N, typename F> __device__ __forceinline__ void band_static_for(F&& f) {   // f(integral_constant<I>) ... <N-1>
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); band_static_for<I + 1, N>(f); }
+}
+template <int N> __device__ __forceinline__ void band_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+
+template <int K, int BN>
+struct BandCfg {
+  static constexpr int TH = 16, TW = 32;
+  static constexpr int IH = TH + K - 1, IW = TW + K - 1, IWp = (IW + 7) & ~7;
+  static constexpr int HROWS = IH * IWp;                 // halo rows (64 bytes each) of one chunk
+  static constexpr int HR = (HROWS + 127) / 128;         // LDS-DMA rounds (512 lanes x 16 bytes = 128 rows) per halo image
+  static constexpr int HB = HROWS * 64;
+  static constexpr int WROWS = K * BN;
+  static constexpr int WR = (WROWS + 127) / 128;
+  static constexpr int WB = WROWS * 64;
+  static constexpr int HPS = (HR + K - 2) / (K - 1);     // halo rounds issued per stage (stages 0 .. K-2 of the previous chunk)
+  static constexpr int RED = 8 * 2 * BN * 4;             // statistics scratch: [8 waves][2][BN] floats
+  static constexpr size_t LDS = 2 * HB + 2 * WB + RED;
+  static_assert(HROWS % 16 == 0 && WROWS % 16 == 0, "a wave's 16 rows of a DMA round are either all inside or all outside the image");
+  static_assert(HPS * (K - 1) >= HR && HPS <= 3, "halo rounds must fit the stages of one chunk");
+};
+
+// One LDS-DMA instruction through a buffer resource: lane address = base + soff + voff; a lane whose voff is not below
+// the resource's num_records fetches zeros (padding, dead channels) — no zero page, no 64-bit address arithmetic.
+typedef __attribute__((ext_vector_type(4))) int band_rsrc_t;
+constexpr int kBandOob = 0x7fffff00;           // num_records of every resource and the voff of a padding lane
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void band_dma(int voff, band_rsrc_t rsrc, unsigned lds_wave_base, int soff) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+               : : "v"(voff), "s"(rsrc), "s"(lds_wave_base), "s"(soff) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ band_rsrc_t band_rsrc(const void* base) {
+  const unsigned long long a = (unsigned long long)base;
+  band_rsrc_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));   // stride 0: raw buffer
+  r[2] = kBandOob;
+  r[3] = 0x00020000;
+  return r;
+}
+
+template <int K, int BN, int VAR>
+__global__ __launch_bounds__(512) void conv_band_kernel(const BandArgs p) {
+  constexpr bool DBG = (VAR & 128) != 0;                  // diagnostic build: honours p.dbg (timing breakdowns, wrong results)
+  const int dbg = DBG ? p.dbg : 0;
+  using C = BandCfg<K, BN>;
+  using T = bf16_t;
+  constexpr int IWp = C::IWp, IW = C::IW, HB = C::HB, WB = C::WB;
+  constexpr int NT_CO = BN / 16, NT_PIX = 4;
+  constexpr int NSTORE = NT_CO * NT_PIX / 2;             // global stores per lane of an interior tile's epilogue
+  static_assert(C::WR + C::HPS <= K, "one DMA instruction per tap slot");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  const int t_begin = blockIdx.x * p.tpw;
+  const int t_end = min(p.ntiles, t_begin + p.tpw);
+  if (t_begin >= t_end) return;                          // (host launches no such workgroup)
+  const int nhalf = p.Cin > 32 ? 2 : 1;
+  const int nchunks = (t_end - t_begin) * nhalf;
+
+  // ---- LDS-DMA source side ----
+  // lane tid fills physical 16-byte slot (tid & 3) of row round*128 + (tid >> 2); it fetches the logical chunk
+  // slot ^ key(row), key = bit 2 of the row -> bit 1 of the slot (LdsRow<1>), the same in every round (128 % 8 == 0)
+  const int rsub = tid >> 2;
+  const int c_l = (tid & 3) ^ ((rsub >> 1) & 2);
+  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);
+  const band_rsrc_t xr = band_rsrc(p.x), wr = band_rsrc(p.wp);
+  const int img_bytes = p.H * p.W * p.ldx * 2;
+
+  auto tile_of = [&](int t, int& b, int& oh0, int& ow0) {
+    b = fast_div(t, p.tiles_hw, p.magic_hw);
+    const int r = t - b * p.tiles_hw;
+    const int ty = fast_div(r, p.tiles_w, p.magic_tw);
+    oh0 = ty * C::TH;
+    ow0 = (r - ty * p.tiles_w) * C::TW;
+  };
+  // byte offsets (inside one image, channel half 0) of this lane's piece of every halo round of a tile
+  int hv[C::HR];
+  auto halo_offsets = [&](int oh0, int ow0) {
+    const int ih0 = oh0 - p.pad_t, iw0 = ow0 - p.pad_l;
+#pragma unroll
+    for (int r = 0; r < C::HR; ++r) {
+      const int row = r * 128 + rsub;
+      const int ih = row / IWp, iw = row - ih * IWp;
+      const int gh = ih0 + ih, gw = iw0 + iw;
+      const bool in = iw < IW && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W && c_l * 8 < p.Cin;
+      hv[r] = in ? ((gh * p.W + gw) * p.ldx + c_l * 8) * 2 : kBandOob;
+    }
+  };
+  auto halo_dma = [&](int r, int soff, int hsel) {         // round r of the image at byte offset soff into halo buffer hsel
+    if (r < C::HR && r * 128 + wave * 16 < C::HROWS) band_dma(hv[r], xr, hsel * HB + r * 8192 + wave_lds, soff);   // wave-uniform
+  };
+  // weights: row tap*BN + m of a stage <- row (j*K + tap)*Mpad + m of the packed [T][Mpad][64] image
+  int wv[C::WR];
+#pragma unroll
+  for (int r = 0; r < C::WR; ++r) {
+    const int row = r * 128 + rsub;
+    const int tap = row / BN, m = min(row % BN, p.Mpad - 1);
+    wv[r] = (tap * p.Mpad + m) * 128 + c_l * 16;
+  }
+  const int wrow_bytes = K * p.Mpad * 128;                 // one kernel row of the packed image
+  auto w_dma = [&](int r, int j, int h, int wsel) {
+    if (r * 128 + wave * 16 < C::WROWS) band_dma(wv[r], wr, 2 * HB + wsel * WB + r * 8192 + wave_lds, j * wrow_bytes + h * 64);
+  };
+
+  // ---- fragment addressing ----
+  int b_k[K];                                             // halo byte offset of (row kw + l15, logical chunk lg)
+#pragma unroll
+  for (int kw = 0; kw < K; ++kw) b_k[kw] = LdsRow<1>::off(kw + l15, lg);
+  const int a_base = LdsRow<1>::off(l15, lg);             // weight row l15 (+ tap*BN + mi*16 rows: key unchanged)
+  const int wave_row = wave * (2 * IWp * 64);
+
+  float bv[NT_CO][4];
+#pragma unroll
+  for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = mi * 16 + 4 * lg + r;
+      bv[mi][r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+    }
+
+  f32x4 acc[NT_CO][NT_PIX];
+  float s1[NT_CO][4], s2[NT_CO][4];
+#pragma unroll
+  for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
+
+  float* const red = reinterpret_cast<float*>(smem + 2 * HB + 2 * WB);
+  auto flush_stats = [&](int grp) {                        // every wave; ends with the sums of `grp` added to p.stats
+#pragma unroll
+    for (int mi = 0; mi < NT_CO; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(s1[mi][r]), c2 = row16_sum(s2[mi][r]);
+        if (l15 == 0) {
+          const int m = mi * 16 + 4 * lg + r;
+          red[(wave * 2 + 0) * BN + m] = a;
+          red[(wave * 2 + 1) * BN + m] = c2;
+        }
+        s1[mi][r] = 0.f; s2[mi][r] = 0.f;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, m = tid - which * BN;
+      if (m < p.Cout) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += red[(w * 2 + which) * BN + m];
+        atomicAdd(p.stats + (long)(blockIdx.x % p.nrep) * p.rep_stride + ((long)grp * 2 + which) * p.stats_ld + m, (double)tot);
+      }
+    }
+  };
+
+  if constexpr ((VAR & 2) != 0) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
+  // ---- prime: the weights of the first kernel row, then the halo of chunk 0 ----
+  int cb, coh0, cow0, ch_half = 0, ct = t_begin;           // current chunk: image, tile origin, channel half, tile
+  tile_of(ct, cb, coh0, cow0);
+  halo_offsets(coh0, cow0);
+#pragma unroll
+  for (int r = 0; r < C::WR; ++r) w_dma(r, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < C::HR; ++r) halo_dma(r, cb * img_bytes, 0);
+  int wsel = 0;
+  bool epi_counted = false;                                // the previous chunk ended with exactly NSTORE stores per lane
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int hsel = c & 1;
+    const bool has_next = c + 1 < nchunks;
+    // next chunk
+    int nb = cb, noh0 = coh0, now0 = cow0, nh = ch_half + 1, nt = ct;
+    if (nh == nhalf) {
+      nh = 0; nt = ct + 1;
+      if (has_next) { tile_of(nt, nb, noh0, now0); halo_offsets(noh0, now0); }
+    }
+    const int nsoff = nb * img_bytes + nh * 64;
+    if (ch_half == 0) {
+#pragma unroll
+      for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT_PIX; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned char* const hb = smem + hsel * HB + wave_row;
+
+    band_static_for<0, K>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      // The weights of this stage (and, entering stage 0, the whole halo image) have landed once at most the operations
+      // issued behind them are outstanding: the halo rounds of the previous stage (counted only where every wave issued
+      // the same number), or the previous tile's epilogue stores (vmcnt retires in issue order).
+      constexpr int r_lo = (j - 1) * C::HPS, r_hi = j * C::HPS < C::HR ? j * C::HPS : C::HR;
+      constexpr bool counted = j >= 1 && r_hi > r_lo && r_hi * 128 <= C::HROWS;
+      if (j == 0 && epi_counted) band_wait<NSTORE>();
+      else if (counted && has_next) band_wait<counted ? r_hi - r_lo : 0>();
+      else band_wait<0>();
+      if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
+
+      const unsigned char* const wl = smem + 2 * HB + wsel * WB + a_base;
+      const unsigned char* const hj = hb + j * (IWp * 64);
+      u32x4 af[2][NT_CO], bf[2][NT_PIX];
+      if constexpr (DBG) if (dbg & 32) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { if (q < NT_CO) af[i][q] = u32x4{0x3f803f80u, (unsigned)tid, 0x3f803f80u, 0x3f803f80u}; bf[i][q] = u32x4{0x3f803f80u, 0x3f803f80u, (unsigned)lane, 0x3f803f80u}; }
+      }
+      auto load = [&](int set, int kw) {
+        if (dbg & 32) return;
+#pragma unroll
+        for (int mi = 0; mi < NT_CO; ++mi) af[set][mi] = *reinterpret_cast<const u32x4*>(wl + kw * (BN * 64) + mi * 1024);
+#pragma unroll
+        for (int ni = 0; ni < NT_PIX; ++ni)
+          bf[set][ni] = *reinterpret_cast<const u32x4*>(hj + b_k[kw] + ((ni >> 1) * IWp + (ni & 1) * 16) * 64);
+      };
+      // DMA slot s of the stage, issued between the fragment reads of tap s+1 and the MFMAs of tap s: first the weights
+      // of the next stage, behind them this stage's share of the next chunk's halo
+      auto dma_slot = [&](int sl) {
+        if (sl < C::WR) {
+          if (dbg & 2) return;
+          if (j + 1 < K) w_dma(sl, j + 1, ch_half, wsel ^ 1);
+          else if (has_next) w_dma(sl, 0, nh, wsel ^ 1);
+        } else if (sl < C::WR + C::HPS) {
+          if (dbg & 1) return;
+          if (has_next && j < K - 1) halo_dma(j * C::HPS + sl - C::WR, nsoff, hsel ^ 1);
+        }
+      };
+      load(0, 0);
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
+        if constexpr ((VAR & 1) != 0) dma_slot(kw);
+        if (kw + 1 < K) load((kw + 1) & 1, kw + 1);
+        if constexpr ((VAR & 1) == 0) dma_slot(kw);
+        if (!(dbg & 4)) {
+#pragma unroll
+          for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT_PIX; ++ni) Mma<T>::run(acc[mi][ni], af[kw & 1][mi], bf[kw & 1][ni]);
+        }
+        if constexpr ((VAR & 4) != 0) {                    // one fragment read per two MFMAs
+#pragma unroll
+          for (int g = 0; g < NT_CO + NT_PIX; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, (NT_CO * NT_PIX) / (NT_CO + NT_PIX), 0);
+          }
+        }
+      }
+      wsel ^= 1;
+    });
+
+    epi_counted = false;
+    if (ch_half == nhalf - 1) {
+      // ---- epilogue of tile ct: bias / activation / store / BatchNorm statistics of the stored values ----
+      const int grp = cb < p.bpg ? 0 : cb / p.bpg;
+      if (p.bias) {
+#pragma unroll
+        for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT_PIX; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] += bv[mi][r];
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT_PIX; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int mi = 0; mi < NT_CO; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT_PIX; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 1.f / (1.f + __expf(-acc[mi][ni][r]));
+      }
+      T* const yb = (T*)p.y + (long)cb * p.Ho * p.Wo * p.ldy;
+      const bool interior = coh0 + C::TH <= p.Ho && cow0 + C::TW <= p.Wo && BN <= p.Cout;   // workgroup-uniform
+      if (interior) {
+        // 16-byte stores: v_permlane16_swap trades the 4 channels a lane holds for pixel tile 2q+1 against the NEXT 4
+        // channels (lane + 16) of pixel tile 2q, so that lane rows 0/2 own 8 consecutive channels of tile 2q and rows
+        // 1/3 of tile 2q+1: half the store instructions of the 8-byte form, the cost that bounds the epilogue
+        T* const d0 = yb + ((long)(coh0 + 2 * wave) * p.Wo + cow0 + (lg & 1) * 16 + l15) * p.ldy + 8 * (lg >> 1);
+#pragma unroll
+        for (int q = 0; q < NT_PIX / 2; ++q) {
+          T* dst = d0 + (long)q * p.Wo * p.ldy;              // pixel tiles 2q, 2q+1: the two 16-pixel halves of one row
+#pragma unroll
+          for (int mi = 0; mi < NT_CO; ++mi) {
+            const f32x4 v0 = acc[mi][2 * q], v1 = acc[mi][2 * q + 1];
+            const u32x2 o0 = u32x2{pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3])};
+            const u32x2 o1 = u32x2{pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3])};
+            if (p.stats) {
+              const f32x4 w0 = f32x4{bflo(o0[0]), bfhi(o0[0]), bflo(o0[1]), bfhi(o0[1])};
+              const f32x4 w1 = f32x4{bflo(o1[0]), bfhi(o1[0]), bflo(o1[1]), bfhi(o1[1])};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                s1[mi][r] += w0[r] + w1[r];
+                s2[mi][r] = fmaf(w1[r], w1[r], fmaf(w0[r], w0[r], s2[mi][r]));
+              }
+            }
+            const u32x2 e0 = __builtin_amdgcn_permlane16_swap(o0[0], o1[0], false, false);
+            const u32x2 e1 = __builtin_amdgcn_permlane16_swap(o0[1], o1[1], false, false);
+            if (!(dbg & 8)) *reinterpret_cast<u32x4*>(dst + mi * 16) = u32x4{e0[0], e1[0], e0[1], e1[1]};
+          }
+        }
+        epi_counted = !(dbg & 8);
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < NT_PIX; ++ni) {
+          const int oh = coh0 + 2 * wave + (ni >> 1), ow = cow0 + (ni & 1) * 16 + l15;
+          const bool valid = oh < p.Ho && ow < p.Wo;
+          T* dst = yb + ((long)oh * p.Wo + ow) * p.ldy;
+#pragma unroll
+          for (int mi = 0; mi < NT_CO; ++mi) {
+            const int co = mi * 16 + 4 * lg;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r];
+            if (valid && co + 3 < p.Cout) {
+              const u32x2 o = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+              *reinterpret_cast<u32x2*>(dst + co) = o;
+              v[0] = bflo(o[0]); v[1] = bfhi(o[0]); v[2] = bflo(o[1]); v[3] = bfhi(o[1]);
+            } else if (valid && co < p.Cout) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                if (co + r < p.Cout) { Elem<T>::st(dst + co + r, v[r]); v[r] = Elem<T>::rnd(v[r]); }
+                else v[r] = 0.f;
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = 0.f;
+            }
+            if (p.stats) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { s1[mi][r] += v[r]; s2[mi][r] = fmaf(v[r], v[r], s2[mi][r]); }
+            }
+          }
+        }
+      }
+      if (p.stats) {
+        const int ngrp = nb < p.bpg ? 0 : nb / p.bpg;
+        if (!has_next || ngrp != grp) { flush_stats(grp); epi_counted = false; }   // workgroup-uniform
+      }
+    }
+    cb = nb; coh0 = noh0; cow0 = now0; ch_half = nh; ct = nt;
+  }
+}
+
+inline bool band_ok(int ntiles) { return ntiles >= 192 && ntiles < 65536; }
+
+template <int K, int BN, int VAR>
+int launch_band_bn(const BandArgs& a, int grid, hipStream_t s) {
+  auto kern = conv_band_kernel<K, BN, VAR>;
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv_band: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  const size_t lds = BandCfg<K, BN>::LDS;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+template <int K>
+int launch_band(BandArgs& a, hipStream_t s) {
+  const int tiles_h = sdhip_cdiv(a.Ho, 16);
+  a.tiles_w = sdhip_cdiv(a.Wo, 32);
+  a.tiles_hw = tiles_h * a.tiles_w;
+  a.ntiles = a.tiles_hw * a.B;
+  a.magic_hw = a.tiles_hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.tiles_hw) + 1u : 0u;
+  a.magic_tw = a.tiles_w > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.tiles_w) + 1u : 0u;
+  a.tpw = sdhip_cdiv(a.ntiles, 256);
+  a.dbg = sdhip_diag().tune_band_dbg;
+  const int grid = sdhip_cdiv(a.ntiles, a.tpw);
+  const int var = (a.dbg >> 8) & 7;
+  a.dbg &= 0xff;
+  if (a.Mpad > 32) {
+    if (a.dbg) return launch_band_bn<K, 64, 128>(a, grid, s);
+    switch (var) {
+      case 1: return launch_band_bn<K, 64, 1>(a, grid, s);
+      case 4: return launch_band_bn<K, 64, 4>(a, grid, s);
+      case 7: return launch_band_bn<K, 64, 0>(a, grid, s);
+      default: return launch_band_bn<K, 64, 5>(a, grid, s);
+    }
+  }
+  return launch_band_bn<K, 32, 5>(a, grid, s);
+}
+
+}  // namespace

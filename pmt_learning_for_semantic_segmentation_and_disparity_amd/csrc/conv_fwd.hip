@@ -16,6 +16,7 @@
 // sum / sum-of-squares for the BatchNorm that follows).
 #include "conv_common.h"
 #include "conv_fast.h"
+#include "conv_band.h"
 #include "conv_gemm.h"
 #include "conv_thin.h"
 
@@ -499,6 +500,17 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     g.M = (long)B * H * W; g.H = H; g.W = W; g.ppg = g.M / groups;
     g.stats_ld = a.stats_ld; g.nrep = a.nrep; g.rep_stride = a.rep_stride;
     if (gemm1x1_ok(g, (in_scale || stats) ? groups : 1)) return launch_gemm_any(g, s);
+  }
+  // ---- persistent whole-CU kernel (conv_band.h): the full-resolution 5x5 layers, bf16, <= 64 channels either side ----
+  if (omul == 1 && dtype == SDHIP_BF16 && kh == 5 && kw == 5 && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
+      !accumulate && Cin % 8 == 0 && (Cin <= 32 || Cin == 64) && a.Mpad <= 64 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
+      (long)B * H * W * ldx * 2 < (long)kBandOob && band_ok(sdhip_cdiv(Ho, 16) * sdhip_cdiv(Wo, 32) * B) && !dg.conv_generic && !dg.conv_no_band) {
+    BandArgs f;
+    f.x = x; f.wp = wpacked; f.y = y; f.bias = bias; f.stats = stats;
+    f.B = B; f.H = H; f.W = W; f.Ho = Ho; f.Wo = Wo; f.pad_t = pad_t; f.pad_l = pad_l;
+    f.Cin = Cin; f.ldx = ldx; f.Cout = Cout; f.Mpad = a.Mpad; f.ldy = ldy;
+    f.bpg = B / groups; f.act = act; f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride;
+    return launch_band<5>(f, s);
   }
   // ---- fast path (conv_fast.h): 16-byte-aligned pixels on both sides, halo-tile mode ----
   if (!per_tap_any && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && a.vec_out &&

@@ -34,6 +34,7 @@ static void diag_fill() {
   g_diag.conv_big = env_set("SDHIP_CONV_BIG");
   g_diag.conv_no_thin = env_set("SDHIP_CONV_NO_THIN");
   g_diag.conv_no_gemm = env_set("SDHIP_CONV_NO_GEMM");
+  g_diag.conv_no_band = env_set("SDHIP_CONV_NO_BAND");
   g_diag.wgrad_generic = env_set("SDHIP_WGRAD_GENERIC");
   g_diag.wgrad_no_pack = env_set("SDHIP_WGRAD_NO_PACK");
   g_diag.wgrad_force_pack = env_set("SDHIP_WGRAD_FORCE_PACK");
@@ -43,6 +44,7 @@ static void diag_fill() {
   g_diag.tune_thin_blocks = env_int("SDHIP_TUNE_THIN_BLOCKS", 1024);
   g_diag.tune_fused_blocks = env_int("SDHIP_TUNE_FUSED_BLOCKS", 768);
   g_diag.tune_gemm_dbg = env_int("SDHIP_TUNE_GEMM_DBG", 0);
+  g_diag.tune_band_dbg = env_int("SDHIP_TUNE_BAND_DBG", 0);
   g_diag.tune_atomic_tbs = getenv("SDHIP_TUNE_ATOMIC_TBS") ? atof(getenv("SDHIP_TUNE_ATOMIC_TBS")) : 1.3;
   g_diag_init = true;
 }

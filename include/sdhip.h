@@ -127,6 +127,20 @@ int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                      int in_relu, int groups, int act, int accumulate,
                      int dtype, void* stream);
 
+/* The data gradient of a stride-1 convolution whose INPUT was relu(BatchNorm_train(u)) — the 3x3 convolution of a DenseNet
+ * layer behind norm2 + relu2 (models/densenet.py:41-45,75-93): y = conv(x, wpacked) is dL/d relu(bn(u)) (x = the gradient
+ * of the convolution's output, wpacked = its weights packed in data-gradient form), and the epilogue, which holds every
+ * value of y once, also takes the two reductions the BatchNorm backward starts with, over the stored (rounded) values:
+ *     sums[rep][g][0][c] += sum_pixels gm * u,   sums[rep][g][1][c] += sum_pixels gm,
+ *     gm = y where u*scale[g][c] + shift[g][c] > 0, else 0
+ * (f64 [sums_nrep][groups][2][sums_ld >= Cout], zeroed by the caller) — what sdhip_affine_act_bwd computes in a pass of its
+ * own over y and u.  u: [B][Ho][Wo] pixels of ldu elements, Cout of them used.  bf16, Cout % 4 == 0; consumer:
+ * sdhip_bn_bwd_apply_fin_d. */
+int sdhip_conv2d_fwd_bnbwd(const void* x, const void* wpacked, void* y, double* sums, int sums_ld, int sums_nrep,
+                           const void* u, int ldu, const float* scale, const float* shift,
+                           int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,
+                           int kh, int kw, int dil, int pad_t, int pad_l, int groups, int dtype, void* stream);
+
 /* One sub-pixel phase of nn.ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1) (models_psmnet/stackhourglass.py:25-29;
  * 2-D: D = kd = 1): output voxel 2m + off of an axis receives input m with kernel tap 1 when off = 0, and inputs m, m+1
  * with taps 2, 0 when off = 1 — so each of the 8 phases (off_d, off_h, off_w) is a stride-1 correlation with a
@@ -242,6 +256,12 @@ int sdhip_bn_bwd_apply_fin(const void* gy, int ldg, const void* x, int ldx, void
                            const float* scale, const float* shift, const float* dscale, const float* dshift, int nrep,
                            const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                            int accumulate_params, long npix, int C, int groups, double count, int act, int dtype, void* stream);
+/* bn_bwd_apply_fin with the two reductions supplied as f64 [nrep][groups][2][C] = (sum(gm*x), sum(gm)) — the layout in
+ * which the epilogue of sdhip_conv2d_fwd_bnbwd adds them. */
+int sdhip_bn_bwd_apply_fin_d(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
+                             const float* scale, const float* shift, const double* sums, int nrep,
+                             const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                             int accumulate_params, long npix, int C, int groups, double count, int act, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Pooling / resizing / broadcast product on NHWC tensors (HBM bound).

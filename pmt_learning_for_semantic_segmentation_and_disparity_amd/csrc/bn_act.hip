@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* gy, int 
                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, int acc_par, int C, long npix_g,
-                                                               double inv_count, int act, RowGeom rg) {
+                                                               double inv_count, int act, const double* __restrict__ dsum, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
   __shared__ float s_a[64 * 8], s_b2[64 * 8];
   __shared__ float s_red[2][8][32];
@@ -346,8 +346,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* gy, int 
     for (int gg = 0; gg < G; ++gg) {
       if (gg != g && !writer) continue;                         // everybody needs its own group; the writer all of them
       float ds = 0.f, dh = 0.f;
-      if (okc)
-        for (int r = rl; r < nrep; r += 8) { ds += dscale[((long)r * G + gg) * C + c]; dh += dshift[((long)r * G + gg) * C + c]; }
+      if (okc) {
+        if (dsum) {   // f64 [nrep][G][2][C] as written by the epilogue of sdhip_conv2d_fwd_bnbwd
+          double d0 = 0., d1 = 0.;
+          for (int r = rl; r < nrep; r += 8) { d0 += dsum[(((long)r * G + gg) * 2 + 0) * C + c]; d1 += dsum[(((long)r * G + gg) * 2 + 1) * C + c]; }
+          ds = (float)d0; dh = (float)d1;
+        } else {
+          for (int r = rl; r < nrep; r += 8) { ds += dscale[((long)r * G + gg) * C + c]; dh += dshift[((long)r * G + gg) * C + c]; }
+        }
+      }
       __syncthreads();
       s_red[0][rl][cl] = ds; s_red[1][rl][cl] = dh;
       __syncthreads();
@@ -792,21 +799,21 @@ extern "C" int sdhip_affine_act_bn(const void* x, int ldx, void* y, int ldy, con
   return SDHIP_OK;
 }
 
-extern "C" int sdhip_bn_bwd_apply_fin(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
-                                      const float* scale, const float* shift, const float* dscale, const float* dshift, int nrep,
+static int bn_bwd_apply_fin_impl(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
+                                 const float* scale, const float* shift, const float* dscale, const float* dshift, const double* dsum, int nrep,
                                       const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                       int accumulate_params, long npix, int C, int groups, double count, int act, int dtype,
                                       void* stream) {
   if (nrep < 1) nrep = 1;
   const int G = groups;
   if (int rc = check_rows("bn_bwd_apply_fin", npix, C, G, dtype)) return rc;
-  SDHIP_CHECK_ARG(gy && x && gx && scale && shift && dscale && dshift && mean && invstd && ldg >= C && ldx >= C && ldgx >= C,
+  SDHIP_CHECK_ARG(gy && x && gx && scale && shift && ((dscale && dshift) || dsum) && mean && invstd && ldg >= C && ldx >= C && ldgx >= C,
                   "bn_bwd_apply_fin: bad pointers/strides");
   SDHIP_CHECK_ARG((act == 0 || act == 1 || act == 2) && count > 0. && (dgamma == nullptr) == (dbeta == nullptr),
                   "bn_bwd_apply_fin: bad arguments");
   hipStream_t s = (hipStream_t)stream;
 #define ARGS(T) (const T*)gy, ldg, (const T*)x, ldx, (T*)gx, ldgx, scale, shift, dscale, dshift, nrep, gamma, mean, invstd, \
-                dgamma, dbeta, accumulate_params, C, npix / G, 1.0 / count, act
+                dgamma, dbeta, accumulate_params, C, npix / G, 1.0 / count, act, dsum
   if (dtype == SDHIP_F32) {
     const bool v = vec_rows<float>(C, {ldg, ldx, ldgx}, {gy, x, gx});
     Plan pl = plan(v ? C / 4 : C, npix / G, G, tune_fused_blocks());
@@ -821,6 +828,26 @@ extern "C" int sdhip_bn_bwd_apply_fin(const void* gy, int ldg, const void* x, in
 #undef ARGS
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
+}
+
+extern "C" int sdhip_bn_bwd_apply_fin(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
+                                      const float* scale, const float* shift, const float* dscale, const float* dshift, int nrep,
+                                      const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                      int accumulate_params, long npix, int C, int groups, double count, int act, int dtype,
+                                      void* stream) {
+  return bn_bwd_apply_fin_impl(gy, ldg, x, ldx, gx, ldgx, scale, shift, dscale, dshift, nullptr, nrep, gamma, mean, invstd, dgamma, dbeta,
+                               accumulate_params, npix, C, groups, count, act, dtype, stream);
+}
+
+// ... with the two reductions given as f64 [nrep][groups][2][C] (sum(gm*x), sum(gm)): the layout the epilogue of
+// sdhip_conv2d_fwd_bnbwd adds them in.
+extern "C" int sdhip_bn_bwd_apply_fin_d(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
+                                        const float* scale, const float* shift, const double* sums, int nrep,
+                                        const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                        int accumulate_params, long npix, int C, int groups, double count, int act, int dtype,
+                                        void* stream) {
+  return bn_bwd_apply_fin_impl(gy, ldg, x, ldx, gx, ldgx, scale, shift, nullptr, nullptr, sums, nrep, gamma, mean, invstd, dgamma, dbeta,
+                               accumulate_params, npix, C, groups, count, act, dtype, stream);
 }
 
 extern "C" int sdhip_channel_stats(const void* x, int ldx, double* stats, int ldc, int nrep, long npix, int C, int groups,

@@ -34,6 +34,11 @@ struct FastArgs {
   // interleaved output (one sub-pixel phase of a stride-2 transposed convolution): output voxel (dz, oh, ow) of image b is
   // stored at (dz*omul + ooz, oh*omul + ooy, ow*omul + oox) of a volume omul times as large per axis.  omul = 1: plain.
   int omul, ooz, ooy, oox;
+  // BatchNorm-backward sums in the epilogue (sdhip_conv2d_fwd_bnbwd): this launch is the data gradient that produces
+  // g = dL/d relu(bn(u)); with u = bx (same geometry as y, pixel stride ldbx) and z = u*bsc + bsh the statistics slots
+  // receive sum(gm * u) and sum(gm), gm = g where z > 0 else 0 — the reductions of sdhip_affine_act_bwd — instead of
+  // sum(y), sum(y^2).  nullptr: plain statistics.
+  const void* bx; const float* bsc; const float* bsh; int ldbx;
 };
 
 // source of every padding / dead lane of an LDS-DMA load
@@ -439,7 +444,41 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   // (accumulating launches take the general path: its per-tile branches keep the old values' loads from being hoisted
   //  together, which would cost ~100 VGPRs — a wave of occupancy — in every launch of this kernel)
   const bool interior = oh0 + TH <= p.Ho && ow0 + TW <= p.Wo && n0 + BN <= p.Cout && !p.accumulate;   // wave-uniform
-  if (interior) {
+  if (p.bx) {   // uniform; host: stats set, Cout % 4 == 0, omul == 1, no accumulate / bias / activation
+    if constexpr (sizeof(T) == 2) {   // bf16 only (host-checked)
+    const T* const ub = (const T*)p.bx + zimg * p.Ho * p.Wo * p.ldbx;
+#pragma unroll
+    for (int mi = 0; mi < NT_CO; ++mi) {
+      const int co = n0 + mi * 16 + 4 * lg;
+      const bool cok = co < p.Cout;
+      f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, sh = sc;
+      if (cok) {
+        sc = *reinterpret_cast<const f32x4*>(p.bsc + (long)grp * p.Cout + co);
+        sh = *reinterpret_cast<const f32x4*>(p.bsh + (long)grp * p.Cout + co);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NT_PIX; ++ni) {
+        const int pt = pt0 + ni;
+        const int oh = oh0 + pt / TWT, ow = ow0 + (pt % TWT) * 16 + l15;
+        if (cok && oh < p.Ho && ow < p.Wo) {
+          const long pix = (long)oh * p.Wo + ow;
+          const u32x2 uu = *reinterpret_cast<const u32x2*>(ub + pix * p.ldbx + co);
+          const f32x4 v = acc[mi][ni];
+          const u32x2 o = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(yb + pix * p.ldy + co) = o;
+          const float g4[4] = {bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1])};
+          const float u4[4] = {bflo(uu[0]), bfhi(uu[0]), bflo(uu[1]), bfhi(uu[1])};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gm = fmaf(u4[r], sc[r], sh[r]) > 0.f ? g4[r] : 0.f;
+            s1[mi][r] = fmaf(gm, u4[r], s1[mi][r]);
+            s2[mi][r] += gm;
+          }
+        }
+      }
+    }
+    }
+  } else if (interior) {
     T* const d0 = yb + ((long)(oh0 + pt0 / TWT) * om * WoD + (ow0 + (pt0 % TWT) * 16 + l15) * om) * p.ldy + n0 + 4 * lg;
 #pragma unroll
     for (int ni = 0; ni < NT_PIX; ++ni) {

@@ -426,7 +426,8 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
                            int kh, int kw, int stride, int dil, int pad_t, int pad_l,
                            int D, int Do, int kd, int sd, int pad_d,
                            int in_relu, int groups, int act, int accumulate,
-                           int dtype, void* stream, int omul, int ooz, int ooy, int oox) {
+                           int dtype, void* stream, int omul, int ooz, int ooy, int oox,
+                           const void* bx = nullptr, int ldbx = 0, const float* bsc = nullptr, const float* bsh = nullptr) {
   SDHIP_CHECK_ARG(x && wpacked && y, "conv2d_fwd: null pointer");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv2d_fwd: unknown dtype %d", dtype);
   SDHIP_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_fwd: empty tensor");
@@ -474,7 +475,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
   hipStream_t s = (hipStream_t)stream;
   const int per_tap_any = (kh > 1 || kw > 1) && dil >= 4 && kd == 1;
   // ---- thin path (conv_thin.h): <= 8 input channels -> 1 output channel on the vector ALUs ----
-  if (omul == 1 && Cout == 1 && Cin <= V && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale &&
+  if (!bx && omul == 1 && Cout == 1 && Cin <= V && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale &&
       !accumulate && kh * kw <= kThinMaxT && Ho == H + 2 * pad_t - dil * (kh - 1) && Wo == W + 2 * pad_l - dil * (kw - 1) &&
       pad_t >= 0 && pad_l >= 0 && !dg.conv_no_thin) {
     ThinArgs t;
@@ -489,7 +490,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     return SDHIP_OK;
   }
   // ---- 1x1 as a streaming GEMM (conv_gemm.h): bf16, plain stride-1 1x1 over whole images ----
-  if (omul == 1 && dtype == SDHIP_BF16 && kh == 1 && kw == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && D == 1 && Do == 1 &&
+  if (!bx && omul == 1 && dtype == SDHIP_BF16 && kh == 1 && kw == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && D == 1 && Do == 1 &&
       Ho == H && Wo == W && !accumulate && !dg.conv_generic && !dg.conv_no_gemm) {
     GemmArgs g;
     g.seg[0] = GemmSeg{x, ldx, Cin, 0};
@@ -502,7 +503,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     if (gemm1x1_ok(g, (in_scale || stats) ? groups : 1)) return launch_gemm_any(g, s);
   }
   // ---- persistent whole-CU kernel (conv_band.h): the full-resolution 5x5 layers, bf16, <= 64 channels either side ----
-  if (omul == 1 && dtype == SDHIP_BF16 && kh == 5 && kw == 5 && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
+  if (!bx && omul == 1 && dtype == SDHIP_BF16 && kh == 5 && kw == 5 && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
       !accumulate && Cin % 8 == 0 && (Cin <= 32 || Cin == 64) && a.Mpad <= 64 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
       (long)B * H * W * ldx * 2 < (long)kBandOob && band_ok(sdhip_cdiv(Ho, 16) * sdhip_cdiv(Wo, 32) * B) && !dg.conv_generic && !dg.conv_no_band) {
     BandArgs f;
@@ -525,6 +526,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     f.in_relu = in_relu; f.bpg = B / groups; f.act = act; f.accumulate = accumulate;
     f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride; f.tail = (Cin % V) != 0;
     f.omul = omul; f.ooz = ooz; f.ooy = ooy; f.oox = oox;
+    f.bx = bx; f.ldbx = ldbx; f.bsc = bsc; f.bsh = bsh;
     f.dma = !in_scale && !f.tail;
     bool fbig = big;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -557,6 +559,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     }
   }
   if (omul != 1) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_phase: interleaved output needs the aligned fast path (ldx %% 8, ldy %% 4)");
+  if (bx) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_bnbwd: needs the aligned fast path (ldx %% 8, ldy %% 4, halo tile within LDS)");
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int th = big ? 8 : 4, tw = big ? 32 : 16;
     const int per_tap = per_tap_any;   // halo would be >= 4x the tile in each direction's holes
@@ -616,6 +619,20 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                                 int dtype, void* stream) {
   return conv2d_fwd_impl(x, wpacked, y, bias, in_scale, in_shift, stats, stats_ld, stats_nrep, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy,
                          kh, kw, stride, dil, pad_t, pad_l, D, Do, kd, sd, pad_d, in_relu, groups, act, accumulate, dtype, stream, 1, 0, 0, 0);
+}
+
+// Data gradient of a stride-1 convolution whose input was relu(BatchNorm(u)): y = the gradient w.r.t. that input, and the
+// epilogue also takes the two reductions of the BatchNorm backward over it (see include/sdhip.h).
+extern "C" int sdhip_conv2d_fwd_bnbwd(const void* x, const void* wpacked, void* y, double* sums, int sums_ld, int sums_nrep,
+                                      const void* u, int ldu, const float* scale, const float* shift,
+                                      int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,
+                                      int kh, int kw, int dil, int pad_t, int pad_l, int groups, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(dtype == SDHIP_BF16, "conv2d_fwd_bnbwd: bf16 only");
+  SDHIP_CHECK_ARG(sums && u && scale && shift && ldu >= Cout && Cout % 4 == 0 && ldu % 4 == 0 && ((uintptr_t)u & 7) == 0 &&
+                  ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
+                  "conv2d_fwd_bnbwd: sums / u / scale / shift missing or misaligned (Cout %% 4, ldu %% 4)");
+  return conv2d_fwd_impl(x, wpacked, y, nullptr, nullptr, nullptr, sums, sums_ld, sums_nrep, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy,
+                         kh, kw, 1, dil, pad_t, pad_l, 1, 1, 1, 1, 0, 0, groups, 0, 0, dtype, stream, 1, 0, 0, 0, u, ldu, scale, shift);
 }
 
 // One sub-pixel phase of a stride-2 transposed convolution (see include/sdhip.h): a stride-1 correlation whose outputs are

@@ -154,11 +154,28 @@ class _DenseBlockFn(torch.autograd.Function):
             # (2) conv2 (3x3): data gradient w.r.t. relu(norm2(y1)), weight gradient
             wd2 = ops.packed_weight(layer.conv2.weight, 'conv', 'dgrad', dtype)
             gp2 = ops.empty_nhwc(B, mid, H, W, dtype, dev)
-            ops._conv_launch(dy2, growth, wd2, gp2, mid, None, None, None, None, B, H, W, growth, H, W, mid, 3, 3, 1, 1, 1, 1,
-                             False, 1, 0, False)
+            fuse2 = training and ops._fused_bn() and dtype == torch.bfloat16 and mid % 8 == 0
+            if fuse2:
+                # ... whose epilogue also takes norm2's two backward reductions (no pass of its own over gp2 and y1)
+                sums2 = ops._zeros((NREP, groups, 2, mid), torch.float64, dev)[0]
+                call("sdhip_conv2d_fwd_bnbwd", ptr(dy2), ptr(wd2), ptr(gp2), ptr(sums2), mid, NREP, ptr(y1), mid,
+                     ptr(sc2), ptr(sh2), B, H, W, growth, growth, H, W, mid, mid, 3, 3, 1, 1, 1, groups, dt, st)
+            else:
+                ops._conv_launch(dy2, growth, wd2, gp2, mid, None, None, None, None, B, H, W, growth, H, W, mid, 3, 3, 1, 1, 1, 1,
+                                 False, 1, 0, False)
             gw2 = _wgrad(y1, mid, dy2, growth, layer.conv2.weight, B, H, W, mid, growth, 3, 1, sc2, sh2, groups, dt)
             # (3) through relu + norm2's affine, (4) norm2's statistics, (5) into y1
-            if training and ops._fused_bn():
+            if fuse2:
+                tg, tb = ops._grad_target(layer.norm2.weight), ops._grad_target(layer.norm2.bias)
+                direct2 = tg is not None and tb is not None
+                dg2 = tg if direct2 else torch.empty(mid, dtype=torch.float32, device=dev)
+                db2 = tb if direct2 else torch.empty(mid, dtype=torch.float32, device=dev)
+                call("sdhip_bn_bwd_apply_fin_d", ptr(gp2), mid, ptr(y1), mid, ptr(gp2), mid, ptr(sc2), ptr(sh2), ptr(sums2), NREP,
+                     ptr(layer.norm2.weight), ptr(mu2), ptr(iv2), ptr(dg2), ptr(db2), int(direct2), npix, mid, groups, float(count),
+                     1, dt, st)
+                if direct2:
+                    dg2 = db2 = None
+            elif training and ops._fused_bn():
                 dg2, db2 = ops.bn_backward_two_phase(gp2, mid, y1, mid, gp2, mid, sc2, sh2, mu2, iv2, layer.norm2.weight,
                                                      layer.norm2.bias, npix, mid, groups, 1, count, dt)   # in place: elementwise
             else:

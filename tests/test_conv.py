@@ -250,3 +250,37 @@ def test_hip_thin_wgrad_tiled(B, H, W, Cin, bias):
     assert err < 1e-4, err
     if bias:
         assert abs(float(gb) - float(g1.float().sum())) <= 1e-3 * max(1.0, abs(float(g1.float().sum())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,Cout,groups", [(4, 64, 128, 32, 128, 2), (2, 33, 47, 32, 128, 1), (4, 16, 32, 32, 128, 2),
+                                                   (2, 20, 36, 64, 64, 1)])
+def test_hip_dgrad_with_bn_backward_sums(B, H, W, Cin, Cout, groups):
+    """sdhip_conv2d_fwd_bnbwd (the 3x3 data gradient of a DenseNet layer with norm2's backward reductions in its epilogue):
+    output bit-identical to the plain launch, sums equal to sdhip_affine_act_bwd's over that output."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd._lib import call, ptr, stream_ptr, dtype_code
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + H)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev).bfloat16().permute(0, 3, 1, 2)
+    u = torch.randn(B, H, W, Cout, generator=g).to(dev).bfloat16().permute(0, 3, 1, 2)
+    w = (torch.randn(Cin, Cout, 3, 3, generator=g) * 0.1).to(dev)             # forward conv Cout -> Cin; this is its data gradient
+    sc = (torch.rand(groups, Cout, generator=g) + 0.5).to(dev)
+    sh = (torch.randn(groups, Cout, generator=g) * 0.3).to(dev)
+    wd = ops.packed_weight(w, 'conv', 'dgrad', torch.bfloat16)
+    dt = dtype_code(x)
+    y0 = ops.empty_nhwc(B, Cout, H, W, torch.bfloat16, dev)
+    ops._conv_launch(x, Cin, wd, y0, Cout, None, None, None, None, B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, False, 1, 0, False)
+    both = torch.zeros(2, ops.NREP, groups, Cout, dtype=torch.float32, device=dev)
+    call("sdhip_affine_act_bwd", ptr(y0), Cout, ptr(u), Cout, None, 0, ptr(sc), ptr(sh), ptr(both[0]), ptr(both[1]), ops.NREP,
+         B * H * W, Cout, groups, 1, 0, 0, dt, stream_ptr())
+    y1 = ops.empty_nhwc(B, Cout, H, W, torch.bfloat16, dev)
+    sums = torch.zeros(ops.NREP, groups, 2, Cout, dtype=torch.float64, device=dev)
+    call("sdhip_conv2d_fwd_bnbwd", ptr(x), ptr(wd), ptr(y1), ptr(sums), Cout, ops.NREP, ptr(u), Cout, ptr(sc), ptr(sh),
+         B, H, W, Cin, Cin, H, W, Cout, Cout, 3, 3, 1, 1, 1, groups, dt, stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    ref = both.double().sum(1)                     # [2][groups][C]
+    got = sums.sum(0).permute(1, 0, 2)             # [2][groups][C]
+    scale = ref.abs().max().item()
+    assert (ref - got).abs().max().item() <= 2e-4 * scale

@@ -103,7 +103,7 @@ def kernel_roofline(dtype, B, H, W):
                 break
             except Exception:
                 pass
-    return {"bound": "mfma", "kernel": "conv_fast_kernel<bf16, 8x32 tile, 64 out-ch block, LDS-DMA> 5x5 64->64 @%dx%dx%d" % (B, H, W),
+    return {"bound": "mfma", "kernel": "conv_band_kernel<5x5, 64 out-ch> (persistent, 16x32 tiles, halo prefetched by LDS-DMA) 64->64 @%dx%dx%d" % (B, H, W),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
             "traffic_source": (src + " (PMC passes of `bench.py --roofline-only`, tools/roofline_profile.sh; not measured in this run)") if src else None,
             "mfma_busy_frac": busy, "algorithmic_bytes": 2 * B * H * W * C * (2 if dtype == torch.bfloat16 else 4) + C * C * 25 * 2,

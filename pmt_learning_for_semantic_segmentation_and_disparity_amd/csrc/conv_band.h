@@ -44,21 +44,24 @@ template <int I, int N, typename F> __device__ __forceinline__ void band_static_
 }
 template <int N> __device__ __forceinline__ void band_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-template <int K, int BN>
+template <int K, int BN, int NW = 8>
 struct BandCfg {
+  static constexpr int RPR = NW * 16;                    // LDS rows (64 bytes) one DMA round of the workgroup fills
+  static constexpr int RPW = 16 / NW;                    // output pixel rows per wave
   static constexpr int TH = 16, TW = 32;
   static constexpr int IH = TH + K - 1, IW = TW + K - 1, IWp = (IW + 7) & ~7;
   static constexpr int HROWS = IH * IWp;                 // halo rows (64 bytes each) of one chunk
-  static constexpr int HR = (HROWS + 127) / 128;         // LDS-DMA rounds (512 lanes x 16 bytes = 128 rows) per halo image
+  static constexpr int HR = (HROWS + RPR - 1) / RPR;     // LDS-DMA rounds (NW x 64 lanes x 16 bytes = RPR rows) per halo image
   static constexpr int HB = HROWS * 64;
   static constexpr int WROWS = K * BN;
-  static constexpr int WR = (WROWS + 127) / 128;
+  static constexpr int WR = (WROWS + RPR - 1) / RPR;
   static constexpr int WB = WROWS * 64;
   static constexpr int HPS = (HR + K - 2) / (K - 1);     // halo rounds issued per stage (stages 0 .. K-2 of the previous chunk)
-  static constexpr int RED = 8 * 2 * BN * 4;             // statistics scratch: [8 waves][2][BN] floats
+  static constexpr int RED = NW * 2 * BN * 4;            // statistics scratch: [NW waves][2][BN] floats
+  static constexpr int SPT = (WR + HPS + K - 1) / K;     // DMA slots per tap
   static constexpr size_t LDS = 2 * HB + 2 * WB + RED;
   static_assert(HROWS % 16 == 0 && WROWS % 16 == 0, "a wave's 16 rows of a DMA round are either all inside or all outside the image");
-  static_assert(HPS * (K - 1) >= HR && HPS <= 3, "halo rounds must fit the stages of one chunk");
+  static_assert(HPS * (K - 1) >= HR, "halo rounds must fit the stages of one chunk");
 };
 
 // One LDS-DMA instruction through a buffer resource: lane address = base + soff + voff; a lane whose voff is not below
@@ -82,16 +85,15 @@ __device__ __forceinline__ band_rsrc_t band_rsrc(const void* base) {
   return r;
 }
 
-template <int K, int BN, int VAR>
-__global__ __launch_bounds__(512) void conv_band_kernel(const BandArgs p) {
+template <int K, int BN, int VAR, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
   constexpr bool DBG = (VAR & 128) != 0;                  // diagnostic build: honours p.dbg (timing breakdowns, wrong results)
   const int dbg = DBG ? p.dbg : 0;
-  using C = BandCfg<K, BN>;
+  using C = BandCfg<K, BN, NW>;
   using T = bf16_t;
-  constexpr int IWp = C::IWp, IW = C::IW, HB = C::HB, WB = C::WB;
-  constexpr int NT_CO = BN / 16, NT_PIX = 4;
+  constexpr int IWp = C::IWp, IW = C::IW, HB = C::HB, WB = C::WB, RPR = C::RPR, RPW = C::RPW;
+  constexpr int NT_CO = BN / 16, NT_PIX = 2 * RPW;
   constexpr int NSTORE = NT_CO * NT_PIX / 2;             // global stores per lane of an interior tile's epilogue
-  static_assert(C::WR + C::HPS <= K, "one DMA instruction per tap slot");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(const BandArgs p) {
     const int ih0 = oh0 - p.pad_t, iw0 = ow0 - p.pad_l;
 #pragma unroll
     for (int r = 0; r < C::HR; ++r) {
-      const int row = r * 128 + rsub;
+      const int row = r * RPR + rsub;
       const int ih = row / IWp, iw = row - ih * IWp;
       const int gh = ih0 + ih, gw = iw0 + iw;
       const bool in = iw < IW && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W && c_l * 8 < p.Cin;
@@ -134,19 +136,19 @@ __global__ __launch_bounds__(512) void conv_band_kernel(const BandArgs p) {
     }
   };
   auto halo_dma = [&](int r, int soff, int hsel) {         // round r of the image at byte offset soff into halo buffer hsel
-    if (r < C::HR && r * 128 + wave * 16 < C::HROWS) band_dma(hv[r], xr, hsel * HB + r * 8192 + wave_lds, soff);   // wave-uniform
+    if (r < C::HR && r * RPR + wave * 16 < C::HROWS) band_dma(hv[r], xr, hsel * HB + r * (RPR * 64) + wave_lds, soff);   // wave-uniform
   };
   // weights: row tap*BN + m of a stage <- row (j*K + tap)*Mpad + m of the packed [T][Mpad][64] image
   int wv[C::WR];
 #pragma unroll
   for (int r = 0; r < C::WR; ++r) {
-    const int row = r * 128 + rsub;
+    const int row = r * RPR + rsub;
     const int tap = row / BN, m = min(row % BN, p.Mpad - 1);
     wv[r] = (tap * p.Mpad + m) * 128 + c_l * 16;
   }
   const int wrow_bytes = K * p.Mpad * 128;                 // one kernel row of the packed image
   auto w_dma = [&](int r, int j, int h, int wsel) {
-    if (r * 128 + wave * 16 < C::WROWS) band_dma(wv[r], wr, 2 * HB + wsel * WB + r * 8192 + wave_lds, j * wrow_bytes + h * 64);
+    if (r < C::WR && r * RPR + wave * 16 < C::WROWS) band_dma(wv[r], wr, 2 * HB + wsel * WB + r * (RPR * 64) + wave_lds, j * wrow_bytes + h * 64);
   };
 
   // ---- fragment addressing ----
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(const BandArgs p) {
 #pragma unroll
   for (int kw = 0; kw < K; ++kw) b_k[kw] = LdsRow<1>::off(kw + l15, lg);
   const int a_base = LdsRow<1>::off(l15, lg);             // weight row l15 (+ tap*BN + mi*16 rows: key unchanged)
-  const int wave_row = wave * (2 * IWp * 64);
+  const int wave_row = wave * (RPW * IWp * 64);
 
   float bv[NT_CO][4];
 #pragma unroll
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(const BandArgs p) {
       if (m < p.Cout) {
         float tot = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) tot += red[(w * 2 + which) * BN + m];
+        for (int w = 0; w < NW; ++w) tot += red[(w * 2 + which) * BN + m];
         atomicAdd(p.stats + (long)(blockIdx.x % p.nrep) * p.rep_stride + ((long)grp * 2 + which) * p.stats_ld + m, (double)tot);
       }
     }
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(const BandArgs p) {
       // issued behind them are outstanding: the halo rounds of the previous stage (counted only where every wave issued
       // the same number), or the previous tile's epilogue stores (vmcnt retires in issue order).
       constexpr int r_lo = (j - 1) * C::HPS, r_hi = j * C::HPS < C::HR ? j * C::HPS : C::HR;
-      constexpr bool counted = j >= 1 && r_hi > r_lo && r_hi * 128 <= C::HROWS;
+      constexpr bool counted = j >= 1 && r_hi > r_lo && r_hi * RPR <= C::HROWS;
       if (j == 0 && epi_counted) band_wait<NSTORE>();
       else if (counted && has_next) band_wait<counted ? r_hi - r_lo : 0>();
       else band_wait<0>();
@@ -274,9 +276,15 @@ __global__ __launch_bounds__(512) void conv_band_kernel(const BandArgs p) {
       load(0, 0);
 #pragma unroll
       for (int kw = 0; kw < K; ++kw) {
-        if constexpr ((VAR & 1) != 0) dma_slot(kw);
+        if constexpr ((VAR & 1) != 0) {
+#pragma unroll
+          for (int sl = kw * C::SPT; sl < (kw + 1) * C::SPT; ++sl) dma_slot(sl);
+        }
         if (kw + 1 < K) load((kw + 1) & 1, kw + 1);
-        if constexpr ((VAR & 1) == 0) dma_slot(kw);
+        if constexpr ((VAR & 1) == 0) {
+#pragma unroll
+          for (int sl = kw * C::SPT; sl < (kw + 1) * C::SPT; ++sl) dma_slot(sl);
+        }
         if (!(dbg & 4)) {
 #pragma unroll
           for (int mi = 0; mi < NT_CO; ++mi)
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(const BandArgs p) {
         // 16-byte stores: v_permlane16_swap trades the 4 channels a lane holds for pixel tile 2q+1 against the NEXT 4
         // channels (lane + 16) of pixel tile 2q, so that lane rows 0/2 own 8 consecutive channels of tile 2q and rows
         // 1/3 of tile 2q+1: half the store instructions of the 8-byte form, the cost that bounds the epilogue
-        T* const d0 = yb + ((long)(coh0 + 2 * wave) * p.Wo + cow0 + (lg & 1) * 16 + l15) * p.ldy + 8 * (lg >> 1);
+        T* const d0 = yb + ((long)(coh0 + RPW * wave) * p.Wo + cow0 + (lg & 1) * 16 + l15) * p.ldy + 8 * (lg >> 1);
 #pragma unroll
         for (int q = 0; q < NT_PIX / 2; ++q) {
           T* dst = d0 + (long)q * p.Wo * p.ldy;              // pixel tiles 2q, 2q+1: the two 16-pixel halves of one row
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(const BandArgs p) {
       } else {
 #pragma unroll
         for (int ni = 0; ni < NT_PIX; ++ni) {
-          const int oh = coh0 + 2 * wave + (ni >> 1), ow = cow0 + (ni & 1) * 16 + l15;
+          const int oh = coh0 + RPW * wave + (ni >> 1), ow = cow0 + (ni & 1) * 16 + l15;
           const bool valid = oh < p.Ho && ow < p.Wo;
           T* dst = yb + ((long)oh * p.Wo + ow) * p.ldy;
 #pragma unroll
@@ -395,17 +403,17 @@ __global__ __launch_bounds__(512) void conv_band_kernel(const BandArgs p) {
 
 inline bool band_ok(int ntiles) { return ntiles >= 192 && ntiles < 65536; }
 
-template <int K, int BN, int VAR>
+template <int K, int BN, int VAR, int NW = 8>
 int launch_band_bn(const BandArgs& a, int grid, hipStream_t s) {
-  auto kern = conv_band_kernel<K, BN, VAR>;
+  auto kern = conv_band_kernel<K, BN, VAR, NW>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv_band: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  const size_t lds = BandCfg<K, BN>::LDS;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+  const size_t lds = BandCfg<K, BN, NW>::LDS;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, a);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }
@@ -421,17 +429,11 @@ int launch_band(BandArgs& a, hipStream_t s) {
   a.tpw = sdhip_cdiv(a.ntiles, 256);
   a.dbg = sdhip_diag().tune_band_dbg;
   const int grid = sdhip_cdiv(a.ntiles, a.tpw);
-  const int var = (a.dbg >> 8) & 7;
+  // VAR 5 = DMA slot ahead of the fragment reads + one read per two MFMAs (sched_group_barrier): 207 -> 201 us against the
+  // other orders; 4 waves (one per SIMD, 64 x 128 register tiles) measured 265 us — the partner wave's cover is worth more
+  // than the quarter of LDS reads saved.  VAR 128: diagnostic build that honours SDHIP_TUNE_BAND_DBG.
   a.dbg &= 0xff;
-  if (a.Mpad > 32) {
-    if (a.dbg) return launch_band_bn<K, 64, 128>(a, grid, s);
-    switch (var) {
-      case 1: return launch_band_bn<K, 64, 1>(a, grid, s);
-      case 4: return launch_band_bn<K, 64, 4>(a, grid, s);
-      case 7: return launch_band_bn<K, 64, 0>(a, grid, s);
-      default: return launch_band_bn<K, 64, 5>(a, grid, s);
-    }
-  }
+  if (a.Mpad > 32) return a.dbg ? launch_band_bn<K, 64, 128 + 5>(a, grid, s) : launch_band_bn<K, 64, 5>(a, grid, s);
   return launch_band_bn<K, 32, 5>(a, grid, s);
 }
 

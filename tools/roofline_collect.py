@@ -30,13 +30,14 @@ def short(n):
 rows = kstats(R + "/stats/r_kernel_stats.csv", "profiles/%s_roofline_kernel_stats.csv" % TAG)
 kstats(R + "/step/r_kernel_stats.csv", "profiles/%s_bench_graph_kernel_stats.csv" % TAG, 60)
 shutil.copy(R + "/step_summary.txt", "profiles/%s_step_summary.txt" % TAG)
-conv = [r for r in rows if "conv_fast_kernel" in r["Name"]][0]
+DOM = "conv_band_kernel" if any("conv_band_kernel" in r["Name"] for r in rows) else "conv_fast_kernel"
+conv = [r for r in rows if DOM in r["Name"]][0]
 avg = lambda acc, pat, name: (lambda v: (sum(v) / len(v), len(v)))([x for k, d in acc.items() if pat in k for x in d.get(name, [])])
-fetch, nf = avg(counters(R + "/fetch/r_counter_collection.csv"), "conv_fast_kernel", "FETCH_SIZE")
-write, nw = avg(counters(R + "/write/r_counter_collection.csv"), "conv_fast_kernel", "WRITE_SIZE")
+fetch, nf = avg(counters(R + "/fetch/r_counter_collection.csv"), DOM, "FETCH_SIZE")
+write, nw = avg(counters(R + "/write/r_counter_collection.csv"), DOM, "WRITE_SIZE")
 m1 = counters(R + "/mfma/r_counter_collection.csv")
-busy, _ = avg(m1, "conv_fast_kernel", "SQ_VALU_MFMA_BUSY_CYCLES")
-sqbusy, _ = avg(m1, "conv_fast_kernel", "SQ_BUSY_CYCLES")
+busy, _ = avg(m1, DOM, "SQ_VALU_MFMA_BUSY_CYCLES")
+sqbusy, _ = avg(m1, DOM, "SQ_BUSY_CYCLES")
 line = [l for l in open(R + "/stats.log") if l.startswith("{")][-1]
 roof = json.loads(line)["roofline"]
 # FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950 -> x2
@@ -66,11 +67,18 @@ for k, d in sf.items():
     fam[short(k)]["fetch"] += sum(d.get("FETCH_SIZE", []))
 for k, d in sw.items():
     fam[short(k)]["write"] += sum(d.get("WRITE_SIZE", []))
-dur = {}
-for r in csv.DictReader(open(R + "/step_mfma/r_counter_collection.csv")):
-    pass
+# average duration per launch of each family, from the kernel trace of the graph-replayed run
+dur = collections.defaultdict(lambda: [0, 0.0])
+for r in csv.DictReader(open(R + "/step/r_kernel_stats.csv")):
+    d = dur[short(r["Name"])]
+    d[0] += int(r["Calls"]); d[1] += float(r["TotalDurationNs"])
 with open("profiles/%s_step_counters.csv" % TAG, "w") as f:
-    f.write("kernel,launches (3 eager steps),SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES,hbm_MB (2*FETCH+WRITE)\n")
+    f.write("kernel,launches (3 eager steps),SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES,hbm_MB (2*FETCH+WRITE),"
+            "hbm_MB_per_launch,avg_us_per_launch (graph run),GB/s,frac_of_8TB/s\n")
     for k, v in sorted(fam.items(), key=lambda kv: -(2 * kv[1]["fetch"] + kv[1]["write"])):
-        f.write('"%s",%d,%.4g,%.4g,%.1f\n' % (k, v["n"], v["busy"], v["sq"], (2 * v["fetch"] + v["write"]) * 1024 / 1e6))
+        mb = (2 * v["fetch"] + v["write"]) * 1024 / 1e6
+        n = max(v["n"], 1)
+        us = dur[k][1] / dur[k][0] / 1e3 if dur[k][0] else 0.0
+        gbs = (mb / n) / us * 1e3 if us else 0.0
+        f.write('"%s",%d,%.4g,%.4g,%.1f,%.2f,%.1f,%.0f,%.3f\n' % (k, v["n"], v["busy"], v["sq"], mb, mb / n, us, gbs, gbs / 8000.0))
 print(open("profiles/%s_step_counters.csv" % TAG).read()[:3000])

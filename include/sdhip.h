@@ -127,6 +127,15 @@ int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                      int in_relu, int groups, int act, int accumulate,
                      int dtype, void* stream);
 
+/* y = conv(x, wpacked) + addend: a data gradient that lands on a tensor with a second consumer — x1 / x2 of Conv2DownUp
+ * (models/dsnet_t2.py:80-117) feed the next convolution AND a skip add — written as the SUM of both contributions (addend =
+ * the skip's gradient, [B][Ho][Wo] pixels of ldadd elements), summed in f32 and rounded once, instead of autograd running an
+ * elementwise add over the map.  Stride 1, no dilation; served by the persistent 5x5 kernel only (bf16, Cin in {8..32, 64},
+ * Cout <= 64, at least 192 tiles of 16x32 output pixels, 16-byte aligned pixels): SDHIP_ERR_UNSUPPORTED otherwise. */
+int sdhip_conv2d_fwd_add(const void* x, const void* wpacked, void* y, const void* addend, int ldadd,
+                         int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,
+                         int kh, int kw, int pad_t, int pad_l, int dtype, void* stream);
+
 /* The data gradient of a stride-1 convolution whose INPUT was relu(BatchNorm_train(u)) — the 3x3 convolution of a DenseNet
  * layer behind norm2 + relu2 (models/densenet.py:41-45,75-93): y = conv(x, wpacked) is dL/d relu(bn(u)) (x = the gradient
  * of the convolution's output, wpacked = its weights packed in data-gradient form), and the epilogue, which holds every

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdhip.so")
 
 F32, BF16 = 0, 1
+ERR_ARG, ERR_LAUNCH, ERR_UNSUPPORTED = -1, -2, -3   # include/sdhip.h
 NREP = int(os.environ.get("SDHIP_TUNE_NREP", "32"))   # statistics replicas the kernels spread their atomics over (env: tuning only)
 
 
@@ -87,6 +88,7 @@ SIGNATURES = {
     "sdhip_flip_sample": [_p, _p, _i, _p, _i, _i, _p, _i, _i, _p, _l, _i, _p],
     "sdhip_bn_bwd_apply_fin": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _d, _i, _i, _p],
     "sdhip_bn_bwd_apply_fin_d": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _d, _i, _i, _p],
+    "sdhip_conv2d_fwd_add": [_p, _p, _p, _p, _i] + [_i] * 14 + [_p],
     "sdhip_conv2d_fwd_bnbwd": [_p, _p, _p, _p, _i, _i, _p, _i, _p, _p] + [_i] * 16 + [_p],
 }
 _lib.sdhip_lovasz_workspace_bytes.argtypes = [_l, _i]
@@ -138,6 +140,8 @@ def _diag_switch(name):
 
 DIAG_NO_FUSED_BN = bool(_diag_switch("SDHIP_DIAG_NO_FUSED_BN"))
 DIAG_NO_SIDE = bool(_diag_switch("SDHIP_DIAG_NO_SIDE"))
+DIAG_NO_GRAD_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_GRAD_SLOTS"))
+DIAG_NO_BNBWD_EPILOGUE = bool(_diag_switch("SDHIP_DIAG_NO_BNBWD_EPILOGUE"))
 DIAG_STEM_S2D = _diag_switch("SDHIP_STEM_S2D")
 
 

@@ -33,6 +33,7 @@ struct BandArgs {
   int B, H, W, Ho, Wo, pad_t, pad_l;
   int Cin, ldx, Cout, Mpad, ldy;
   int bpg, act, stats_ld, nrep;
+  const void* res; int ldres;              // y = result + res (same geometry as y; res == y: accumulate in place); nullptr: off
   long rep_stride;
   int tiles_w, tiles_hw, ntiles, tpw;      // tiles per output row / per image / in total / per workgroup
   unsigned magic_hw, magic_tw;             // div_magic(tiles_hw), div_magic(tiles_w)
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
             for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 1.f / (1.f + __expf(-acc[mi][ni][r]));
       }
       T* const yb = (T*)p.y + (long)cb * p.Ho * p.Wo * p.ldy;
+      const T* const rb = (const T*)p.res + (long)cb * p.Ho * p.Wo * p.ldres;
       const bool interior = coh0 + C::TH <= p.Ho && cow0 + C::TW <= p.Wo && BN <= p.Cout;   // workgroup-uniform
       if (interior) {
         // 16-byte stores: v_permlane16_swap trades the 4 channels a lane holds for pixel tile 2q+1 against the NEXT 4
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
 #pragma unroll
         for (int q = 0; q < NT_PIX / 2; ++q) {
           T* dst = d0 + (long)q * p.Wo * p.ldy;              // pixel tiles 2q, 2q+1: the two 16-pixel halves of one row
+          const T* rsrc = rb + ((long)(coh0 + RPW * wave + q) * p.Wo + cow0 + (lg & 1) * 16 + l15) * p.ldres + 8 * (lg >> 1);
 #pragma unroll
           for (int mi = 0; mi < NT_CO; ++mi) {
             const f32x4 v0 = acc[mi][2 * q], v1 = acc[mi][2 * q + 1];
@@ -353,18 +356,36 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
                 s2[mi][r] = fmaf(w1[r], w1[r], fmaf(w0[r], w0[r], s2[mi][r]));
               }
             }
-            const u32x2 e0 = __builtin_amdgcn_permlane16_swap(o0[0], o1[0], false, false);
-            const u32x2 e1 = __builtin_amdgcn_permlane16_swap(o0[1], o1[1], false, false);
-            if (!(dbg & 8)) *reinterpret_cast<u32x4*>(dst + mi * 16) = u32x4{e0[0], e1[0], e0[1], e1[1]};
+            u32x4 o;
+            if (p.res) {                                     // uniform: y = result + res, summed in f32 and rounded once
+              float f[8];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                // (scalars first: __builtin_bit_cast on a vector ELEMENT reads element 0 under hipcc 7.2, see sdhip_common.h)
+                const float a0 = v0[r], a1 = v1[r];
+                const u32x2 e = __builtin_amdgcn_permlane16_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
+                const unsigned e0 = e[0], e1 = e[1];
+                f[r] = __uint_as_float(e0); f[4 + r] = __uint_as_float(e1);
+              }
+              const u32x4 old = *reinterpret_cast<const u32x4*>(rsrc + mi * 16);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = pack2bf(f[2 * e] + bflo(old[e]), f[2 * e + 1] + bfhi(old[e]));
+            } else {
+              const u32x2 e0 = __builtin_amdgcn_permlane16_swap(o0[0], o1[0], false, false);
+              const u32x2 e1 = __builtin_amdgcn_permlane16_swap(o0[1], o1[1], false, false);
+              o = u32x4{e0[0], e1[0], e0[1], e1[1]};
+            }
+            if (!(dbg & 8)) *reinterpret_cast<u32x4*>(dst + mi * 16) = o;
           }
         }
-        epi_counted = !(dbg & 8);
+        epi_counted = !(dbg & 8) && !p.res;              // (the addend's loads sit among the stores)
       } else {
 #pragma unroll
         for (int ni = 0; ni < NT_PIX; ++ni) {
           const int oh = coh0 + RPW * wave + (ni >> 1), ow = cow0 + (ni & 1) * 16 + l15;
           const bool valid = oh < p.Ho && ow < p.Wo;
           T* dst = yb + ((long)oh * p.Wo + ow) * p.ldy;
+          const T* rsrc = rb + ((long)oh * p.Wo + ow) * p.ldres;
 #pragma unroll
           for (int mi = 0; mi < NT_CO; ++mi) {
             const int co = mi * 16 + 4 * lg;
@@ -372,13 +393,20 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r];
             if (valid && co + 3 < p.Cout) {
+              if (p.res) {
+                const u32x2 old = *reinterpret_cast<const u32x2*>(rsrc + co);
+                v[0] += bflo(old[0]); v[1] += bfhi(old[0]); v[2] += bflo(old[1]); v[3] += bfhi(old[1]);
+              }
               const u32x2 o = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
               *reinterpret_cast<u32x2*>(dst + co) = o;
               v[0] = bflo(o[0]); v[1] = bfhi(o[0]); v[2] = bflo(o[1]); v[3] = bfhi(o[1]);
             } else if (valid && co < p.Cout) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                if (co + r < p.Cout) { Elem<T>::st(dst + co + r, v[r]); v[r] = Elem<T>::rnd(v[r]); }
+                if (co + r < p.Cout) {
+                  if (p.res) v[r] += Elem<T>::ld(rsrc + co + r);
+                  Elem<T>::st(dst + co + r, v[r]); v[r] = Elem<T>::rnd(v[r]);
+                }
                 else v[r] = 0.f;
               }
             } else {

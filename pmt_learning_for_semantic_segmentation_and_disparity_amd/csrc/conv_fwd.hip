@@ -427,7 +427,8 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
                            int D, int Do, int kd, int sd, int pad_d,
                            int in_relu, int groups, int act, int accumulate,
                            int dtype, void* stream, int omul, int ooz, int ooy, int oox,
-                           const void* bx = nullptr, int ldbx = 0, const float* bsc = nullptr, const float* bsh = nullptr) {
+                           const void* bx = nullptr, int ldbx = 0, const float* bsc = nullptr, const float* bsh = nullptr,
+                           const void* addend = nullptr, int ldadd = 0) {
   SDHIP_CHECK_ARG(x && wpacked && y, "conv2d_fwd: null pointer");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv2d_fwd: unknown dtype %d", dtype);
   SDHIP_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_fwd: empty tensor");
@@ -475,7 +476,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
   hipStream_t s = (hipStream_t)stream;
   const int per_tap_any = (kh > 1 || kw > 1) && dil >= 4 && kd == 1;
   // ---- thin path (conv_thin.h): <= 8 input channels -> 1 output channel on the vector ALUs ----
-  if (!bx && omul == 1 && Cout == 1 && Cin <= V && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale &&
+  if (!bx && !addend && omul == 1 && Cout == 1 && Cin <= V && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale &&
       !accumulate && kh * kw <= kThinMaxT && Ho == H + 2 * pad_t - dil * (kh - 1) && Wo == W + 2 * pad_l - dil * (kw - 1) &&
       pad_t >= 0 && pad_l >= 0 && !dg.conv_no_thin) {
     ThinArgs t;
@@ -490,7 +491,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     return SDHIP_OK;
   }
   // ---- 1x1 as a streaming GEMM (conv_gemm.h): bf16, plain stride-1 1x1 over whole images ----
-  if (!bx && omul == 1 && dtype == SDHIP_BF16 && kh == 1 && kw == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && D == 1 && Do == 1 &&
+  if (!bx && !addend && omul == 1 && dtype == SDHIP_BF16 && kh == 1 && kw == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && D == 1 && Do == 1 &&
       Ho == H && Wo == W && !accumulate && !dg.conv_generic && !dg.conv_no_gemm) {
     GemmArgs g;
     g.seg[0] = GemmSeg{x, ldx, Cin, 0};
@@ -504,15 +505,17 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
   }
   // ---- persistent whole-CU kernel (conv_band.h): the full-resolution 5x5 layers, bf16, <= 64 channels either side ----
   if (!bx && omul == 1 && dtype == SDHIP_BF16 && kh == 5 && kw == 5 && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
-      !accumulate && Cin % 8 == 0 && (Cin <= 32 || Cin == 64) && a.Mpad <= 64 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
+      !((accumulate || addend) && stats) && !(accumulate && addend) && (!addend || (ldadd % 8 == 0 && ((uintptr_t)addend & 15) == 0)) && Cin % 8 == 0 && (Cin <= 32 || Cin == 64) && a.Mpad <= 64 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
       (long)B * H * W * ldx * 2 < (long)kBandOob && band_ok(sdhip_cdiv(Ho, 16) * sdhip_cdiv(Wo, 32) * B) && !dg.conv_generic && !dg.conv_no_band) {
     BandArgs f;
     f.x = x; f.wp = wpacked; f.y = y; f.bias = bias; f.stats = stats;
     f.B = B; f.H = H; f.W = W; f.Ho = Ho; f.Wo = Wo; f.pad_t = pad_t; f.pad_l = pad_l;
     f.Cin = Cin; f.ldx = ldx; f.Cout = Cout; f.Mpad = a.Mpad; f.ldy = ldy;
     f.bpg = B / groups; f.act = act; f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride;
+    f.res = addend ? addend : (accumulate ? y : nullptr); f.ldres = addend ? ldadd : ldy;
     return launch_band<5>(f, s);
   }
+  if (addend) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_add: only the persistent 5x5 kernel adds a second tensor in its epilogue (bf16, <= 64 channels, >= 192 tiles of 16x32)");
   // ---- fast path (conv_fast.h): 16-byte-aligned pixels on both sides, halo-tile mode ----
   if (!per_tap_any && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && a.vec_out &&
       (long)H * W * ldx < (1L << 31) && !dg.conv_generic) {
@@ -619,6 +622,15 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                                 int dtype, void* stream) {
   return conv2d_fwd_impl(x, wpacked, y, bias, in_scale, in_shift, stats, stats_ld, stats_nrep, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy,
                          kh, kw, stride, dil, pad_t, pad_l, D, Do, kd, sd, pad_d, in_relu, groups, act, accumulate, dtype, stream, 1, 0, 0, 0);
+}
+
+// y = conv(x) + addend (see include/sdhip.h).
+extern "C" int sdhip_conv2d_fwd_add(const void* x, const void* wpacked, void* y, const void* addend, int ldadd,
+                                    int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,
+                                    int kh, int kw, int pad_t, int pad_l, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(addend && ldadd >= Cout, "conv2d_fwd_add: addend missing / pixel stride smaller than Cout");
+  return conv2d_fwd_impl(x, wpacked, y, nullptr, nullptr, nullptr, nullptr, 0, 1, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy,
+                         kh, kw, 1, 1, pad_t, pad_l, 1, 1, 1, 1, 0, 0, 1, 0, 0, dtype, stream, 1, 0, 0, 0, nullptr, 0, nullptr, nullptr, addend, ldadd);
 }
 
 // Data gradient of a stride-1 convolution whose input was relu(BatchNorm(u)): y = the gradient w.r.t. that input, and the

@@ -325,15 +325,17 @@ __global__ void pack_batch_kernel(const long* __restrict__ desc) {
   const int M = (int)d[2], K = (int)d[3], Tn = (int)d[4], flip = (int)d[7];
   const long sm = d[5], sk = d[6];
   const int Mpad = (M + 15) & ~15;
-  const long total = (long)((K + CK - 1) / CK) * Tn * Mpad * CK;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % CK);
-    long r = i / CK;
-    const int m = (int)(r % Mpad); r /= Mpad;
-    const int t = (int)(r % Tn);
-    const int k = (int)(r / Tn) * CK + c;
+  // 32-bit index arithmetic throughout (a layer's packed image has at most a few million elements): the 64-bit divisions of the first version were most of this kernel's 120 us
+  const unsigned total = (unsigned)((K + CK - 1) / CK) * Tn * Mpad * CK;
+  const unsigned per_q = (unsigned)Tn * Mpad;                 // (tap, m) rows per channel chunk
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned c = i % CK;                                 // CK is a power of two
+    const unsigned r = i / CK;
+    const unsigned q = r / per_q, rr = r - q * per_q;
+    const unsigned t = rr / Mpad, m = rr - t * Mpad;
+    const unsigned k = q * CK + c;
     float v = 0.f;
-    if (m < M && k < K) v = src[m * sm + k * sk + (flip ? Tn - 1 - t : t)];
+    if (m < (unsigned)M && k < (unsigned)K) v = src[(long)m * sm + (long)k * sk + (flip ? Tn - 1 - (int)t : (int)t)];
     Elem<T>::st(dst + i, v);
   }
 }
@@ -355,14 +357,13 @@ __global__ void unpack_batch_kernel(const long* __restrict__ desc, int CK) {
   const int M = (int)d[2], K = (int)d[3], Tn = (int)d[4], flip = (int)d[7];
   const long sm = d[5], sk = d[6];
   const int Mpad = (M + 15) & ~15;
-  const long total = (long)M * K * Tn;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int t = (int)(i % Tn);
-    long r = i / Tn;
-    const int k = (int)(r % K);
-    const int m = (int)(r / K);
-    const int tt = flip ? Tn - 1 - t : t;
-    grad[m * sm + k * sk + t] += acc[(((long)(k / CK) * Tn + tt) * Mpad + m) * CK + (k % CK)];
+  const unsigned total = (unsigned)M * K * Tn;                 // 32-bit index arithmetic (see pack_batch_kernel)
+  const unsigned ckshift = CK == 64 ? 6 : 5;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / Tn, t = i - r * Tn;
+    const unsigned m = r / K, k = r - m * K;
+    const unsigned tt = flip ? Tn - 1 - t : t;
+    grad[(long)m * sm + (long)k * sk + t] += acc[(((long)(k >> ckshift) * Tn + tt) * Mpad + m) * CK + (k & (CK - 1))];
   }
 }
 

@@ -154,7 +154,7 @@ class _DenseBlockFn(torch.autograd.Function):
             # (2) conv2 (3x3): data gradient w.r.t. relu(norm2(y1)), weight gradient
             wd2 = ops.packed_weight(layer.conv2.weight, 'conv', 'dgrad', dtype)
             gp2 = ops.empty_nhwc(B, mid, H, W, dtype, dev)
-            fuse2 = training and ops._fused_bn() and dtype == torch.bfloat16 and mid % 8 == 0
+            fuse2 = training and ops._fused_bn() and dtype == torch.bfloat16 and mid % 8 == 0 and not _lib_mod.DIAG_NO_BNBWD_EPILOGUE
             if fuse2:
                 # ... whose epilogue also takes norm2's two backward reductions (no pass of its own over gp2 and y1)
                 sums2 = ops._zeros((NREP, groups, 2, mid), torch.float64, dev)[0]

@@ -78,8 +78,8 @@ class conv2dSame(nn.Module):
     def run(self, x, act=0):
         return ops.conv2d(x, self.c2d.weight, self.c2d.bias, act=act, **self._geom())
 
-    def run_bn(self, x, bn, act=0, residual=None, groups=1):
-        return ops.conv_bn_act(x, self.c2d.weight, bn, act=act, residual=residual, groups=groups, **self._geom())
+    def run_bn(self, x, bn, act=0, residual=None, groups=1, **slots):
+        return ops.conv_bn_act(x, self.c2d.weight, bn, act=act, residual=residual, groups=groups, **slots, **self._geom())
 
     def forward(self, x):
         return self.run(x)
@@ -106,11 +106,13 @@ class ConvTranspose2dSame(nn.Module):
             return ops.deconv2d_strided(x, c.weight, c.bias, c.stride[0], act=act)
         return ops.conv2d(x, c.weight, c.bias, act=act, **self._geom())
 
-    def run_bn(self, x, bn, act=0, residual=None, groups=1):
+    def run_bn(self, x, bn, act=0, residual=None, groups=1, **slots):
         c = self.ct2d
         if c.stride[0] != 1:
+            if slots.get("in_slot") is not None or slots.get("res_slot") is not None:
+                raise NotImplementedError("gradient slots are wired for the stride-1 blocks only")
             return ops.deconv2d_strided(x, c.weight, None, c.stride[0], bn=bn, act=act, residual=residual, groups=groups)
-        return ops.conv_bn_act(x, c.weight, bn, act=act, residual=residual, groups=groups, **self._geom())
+        return ops.conv_bn_act(x, c.weight, bn, act=act, residual=residual, groups=groups, **slots, **self._geom())
 
     def forward(self, x):
         return self.run(x)
@@ -128,13 +130,16 @@ class convbn(nn.Module):
         self.layers = nn.Sequential(*seq)
         _he_init(self.modules())
 
-    def fused(self, x, act=0, residual=None, groups=1):
-        """conv -> BatchNorm (batch statistics from the conv epilogue) -> activation (-> + residual): one autograd node."""
+    def fused(self, x, act=0, residual=None, groups=1, **slots):
+        """conv -> BatchNorm (batch statistics from the conv epilogue) -> activation (-> + residual): one autograd node.
+        slots: in_slot / res_slot of ops.conv_bn_act."""
         conv = self.layers[0]
         if len(self.layers) == 1:
+            if any(v is not None for v in slots.values()):
+                raise NotImplementedError("gradient slots need the BatchNorm form of the block")
             y = conv.run(x, act=act)
             return y if residual is None else ops.affine_act(y, None, None, residual, 0)
-        return conv.run_bn(x, self.layers[1], act=act, residual=residual, groups=groups)
+        return conv.run_bn(x, self.layers[1], act=act, residual=residual, groups=groups, **slots)
 
     def forward(self, x):
         return self.fused(x)
@@ -149,14 +154,17 @@ def _act_block(block, p=0.0):
     return nn.Sequential(block, nn.ReLU(inplace=True), nn.Dropout(p=p))
 
 
-def run_act_block(seq, x, residual=None, groups=1):
+def run_act_block(seq, x, residual=None, groups=1, in_slot=None, res_slot=None):
     """Sequential(convbn|deconvbn, ReLU[, Dropout]) as one fused conv+BN+ReLU(+skip).  With Dropout(p > 0) in training
     mode (models/dsnet_t2.py:85-93; the shipped recipe has p = 0) the mask sits between the ReLU and the skip add, so the
     skip is added after the dropout kernel instead of inside the BatchNorm pass."""
     if len(seq) > 2 and seq[2].p and seq[2].training:
         y = ops.dropout(seq[0].fused(x, act=1, groups=groups), seq[2].p, True, _dropout_id(seq[2]))
         return y if residual is None else ops.add(y, residual)
-    return seq[0].fused(x, act=1, residual=residual, groups=groups)
+    return seq[0].fused(x, act=1, residual=residual, groups=groups, in_slot=in_slot, res_slot=res_slot)
+
+
+GRAD_SLOTS = not ops._lib.DIAG_NO_GRAD_SLOTS    # tests / diagnostics (SDHIP_DIAG_NO_GRAD_SLOTS): False hands every skip gradient back to autograd (one elementwise add each)
 
 
 class Conv2DownUp(nn.Module):
@@ -175,11 +183,19 @@ class Conv2DownUp(nn.Module):
         self.d5 = _act_block(deconvbn(o, o, k, 1, 'same', 1), dropout)
 
     def forward(self, x, groups=1):
+        # x1 feeds c2 and (skip) d4, x2 feeds c3 and (skip) d3: in the backward pass the skip gradient is parked in a
+        # GradSlot and the data gradient of c2 / c3 is accumulated onto it by the convolution launch itself (ops.GradSlot)
+        slotted = GRAD_SLOTS and torch.is_grad_enabled() and x.is_cuda and len(self.c1[0].layers) > 1 and \
+            not any(len(b) > 2 and b[2].p and b[2].training for b in (self.c2, self.c3, self.d3, self.d4))
+        # d3's incoming gradient is d4's fresh data gradient (exclusive); d4's is d5's — or, without d5, whatever the rest
+        # of the network hands in, which is only read
+        s1 = ops.GradSlot(exclusive=self.lastLayer) if slotted else None
+        s2 = ops.GradSlot(exclusive=True) if slotted else None
         x1 = run_act_block(self.c1, x, groups=groups)
-        x2 = run_act_block(self.c2, x1, groups=groups)
-        x = run_act_block(self.c3, x2, groups=groups)
-        x = run_act_block(self.d3, x, residual=x2, groups=groups)
-        x = run_act_block(self.d4, x, residual=x1, groups=groups)
+        x2 = run_act_block(self.c2, x1, groups=groups, in_slot=s1)
+        x = run_act_block(self.c3, x2, groups=groups, in_slot=s2)
+        x = run_act_block(self.d3, x, residual=x2, groups=groups, res_slot=s2)
+        x = run_act_block(self.d4, x, residual=x1, groups=groups, res_slot=s1)
         return run_act_block(self.d5, x, groups=groups) if self.lastLayer else x
 
 

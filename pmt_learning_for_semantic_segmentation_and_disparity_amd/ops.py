@@ -427,7 +427,24 @@ def _bn_backward(gy, ldg, x, ldx, gx, ldgx, scale, shift, mean, invstd, gamma, n
     return (None, None, dstats) if direct else (dgamma, dbeta, dstats)
 
 
-def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_relu, groups, need_x, need_w, bias=None):
+class GradSlot:
+    """Carries one gradient contribution from the autograd node that produces it FIRST in the backward pass to the node
+    whose data-gradient launch can add to it in place.  Conv2DownUp (models/dsnet_t2.py:80-117): x1 feeds c2 and, as a skip,
+    d4 — d4's backward runs before c2's (it was created later), parks the skip gradient here instead of handing it to
+    autograd, and c2's data gradient is launched with accumulate = 1 on that buffer: the sum of the two contributions
+    costs no pass of its own (autograd would run an elementwise add over the full-resolution map)."""
+    __slots__ = ("g", "exclusive")
+
+    def __init__(self, exclusive):
+        # exclusive: the parked tensor is referenced by nobody else (it is the fresh data gradient of the node behind the
+        # parking one), so the sum may be formed IN it; otherwise it is only read (sdhip_conv2d_fwd_add) — an incoming
+        # gradient from outside the block may be shared with another branch of the graph
+        self.g = None
+        self.exclusive = exclusive
+
+
+def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_relu, groups, need_x, need_w, bias=None, acc_into=None,
+                   addend=None):
     has_bias = bias is not None
     """dgrad (w.r.t. the post-prologue input) and wgrad of one conv; returns (g_post, gw, gb)."""
     spec = ctx_spec
@@ -438,7 +455,10 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
     gpost = gw = gb = None
     if need_x:
         wd = packed_weight(weight, spec.kind, 'dgrad', xv.dtype)
-        gpost, ldgp = alloc_nhwc(Bimg, Cin, H, W, xv.dtype, xv.device)
+        if acc_into is not None:
+            gpost, ldgp = nhwc_view(acc_into)     # holds the other contribution: this launch adds to it
+        else:
+            gpost, ldgp = alloc_nhwc(Bimg, Cin, H, W, xv.dtype, xv.device)
         pt = spec.dil * (spec.kh - 1) - spec.pad_t
         pl = spec.dil * (spec.kw - 1) - spec.pad_l
         pd = (spec.kd - 1) - spec.pad_d
@@ -450,8 +470,19 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
             call("sdhip_stuff", ptr(g), ldg, ptr(gsrc), Cout, B, spec.Do, spec.Ho, spec.Wo, Cout, spec.sd, spec.stride, 1, dt,
                  stream_ptr())
             ldsrc = Cout
-        _conv_launch(gsrc, ldsrc, wd, gpost, ldgp, None, None, None, None, B, Hg, Wg, Cout, H, W, Cin,
-                     spec.kh, spec.kw, 1, spec.dil, pt, pl, False, 1, 0, False, 1, (Dg, spec.D, spec.kd, 1, pd))
+        fused_add = False
+        if addend is not None and spec.kd == 1 and spec.D == 1 and spec.dil == 1 and gsrc is g:
+            av, lda = nhwc_view(addend)
+            rc = _lib._lib.sdhip_conv2d_fwd_add(ptr(gsrc), ptr(wd), ptr(gpost), ptr(av), lda, B, Hg, Wg, Cout, ldsrc, H, W, Cin, ldgp,
+                                                spec.kh, spec.kw, pt, pl, dtype_code(xv), stream_ptr())
+            if rc not in (0, _lib.ERR_UNSUPPORTED):
+                raise _lib.SdhipError("sdhip_conv2d_fwd_add failed (%d): %s" % (rc, _lib._lib.sdhip_last_error().decode()))
+            fused_add = rc == 0
+        if not fused_add:
+            _conv_launch(gsrc, ldsrc, wd, gpost, ldgp, None, None, None, None, B, Hg, Wg, Cout, H, W, Cin,
+                         spec.kh, spec.kw, 1, spec.dil, pt, pl, False, 1, 0, acc_into is not None, 1, (Dg, spec.D, spec.kd, 1, pd))
+            if addend is not None:            # no kernel on this shape's path adds a second tensor: one elementwise pass
+                gpost = add(gpost, addend)
     if need_w:
         gw, gb = wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu, groups)
     return gpost, gw, gb
@@ -559,8 +590,9 @@ class _ConvBNActFn(torch.autograd.Function):
     normalises, activates and adds the skip.  convbn / deconvbn (+ReLU, + skip add) of models/dsnet_t2.py:16-117."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, spec, bn, act, groups):
+    def forward(ctx, x, weight, gamma, beta, residual, spec, bn, act, groups, in_slot=None, res_slot=None):
         _require_gpu(x, weight)
+        ctx.in_slot, ctx.res_slot = in_slot, res_slot
         Bimg, Cin, H, W = x.shape
         Btrue = Bimg // spec.D
         B = Btrue * spec.Do                      # output images
@@ -617,9 +649,21 @@ class _ConvBNActFn(torch.autograd.Function):
         else:
             dgamma, dbeta, dS = _bn_backward(g, ldg, yraw, ldraw, graw, ldgr, scale, shift, mean, invstd, gamma, npix, Cout,
                                              groups, ctx.act, ctx.count, ctx.train, dt, beta=beta)
+        acc = addend = None
+        if ctx.in_slot is not None and ctx.in_slot.g is not None and ctx.needs_input_grad[0]:
+            parked, ctx.in_slot.g = ctx.in_slot.g, None       # the skip consumer of x already ran: add to its contribution
+            if parked.shape != xv.shape or parked.dtype != xv.dtype:
+                raise _lib.SdhipError("GradSlot: parked gradient does not match the input it belongs to")
+            if ctx.in_slot.exclusive:
+                acc = parked
+            else:
+                addend = parked
         gx, gw, _ = _conv_backward(spec, xv, ctx.ldx, weight, graw, ldgr, None, None, False, 1, ctx.needs_input_grad[0],
-                                   ctx.needs_input_grad[1])
-        return gx, gw, dgamma, dbeta, (gy if ctx.has_res else None), None, None, None, None
+                                   ctx.needs_input_grad[1], acc_into=acc, addend=addend)
+        gres = gy if ctx.has_res else None
+        if gres is not None and ctx.res_slot is not None:
+            ctx.res_slot.g, gres = gy, None                   # handed to the producer-side consumer of the skip tensor instead
+        return gx, gw, dgamma, dbeta, gres, None, None, None, None, None, None
 
 
 class _BNConvFn(torch.autograd.Function):
@@ -816,9 +860,12 @@ def conv2d(x, weight, bias=None, *, kind='conv', stride=1, dilation=1, padding=0
     return _ConvFn.apply(x, weight, bias, conv_spec(x, weight, kind, stride, dilation, padding), act)
 
 
-def conv_bn_act(x, weight, bn, *, kind='conv', stride=1, dilation=1, padding=0, act=0, residual=None, groups=1):
+def conv_bn_act(x, weight, bn, *, kind='conv', stride=1, dilation=1, padding=0, act=0, residual=None, groups=1,
+                in_slot=None, res_slot=None):
+    """in_slot / res_slot (GradSlot, optional): the gradient of `residual` is parked in res_slot instead of being returned
+    to autograd, and a gradient parked in in_slot is summed into this node's data gradient by its own launch."""
     return _ConvBNActFn.apply(x, weight, bn.weight, bn.bias, residual, conv_spec(x, weight, kind, stride, dilation, padding),
-                              bn, act, groups)
+                              bn, act, groups, in_slot, res_slot)
 
 
 def bn_conv(x, stats, bn, weight, *, padding=0, groups=1):

@@ -117,3 +117,61 @@ def test_band_conv_statistics_match_old_kernel(B, ci, co, H, W, groups):
     assert (yplain - yplain0).abs().max().item() <= 2e-2 * yplain0.abs().max().item()
     assert ((yplain != yplain0).float().mean().item()) < 0.2
     assert torch.allclose(rm, rm0, rtol=1e-3, atol=1e-4) and torch.allclose(rv, rv0, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,ci,co,H,W", [(2, 64, 64, 100, 450), (4, 32, 64, 96, 256)])
+def test_band_conv_sums_a_second_tensor(B, ci, co, H, W):
+    """y = conv(x) + addend (sdhip_conv2d_fwd_add) and y += conv(x) (accumulate) of the band kernel: the sum is formed in
+    f32 from the unrounded convolution and rounded once — never further from the f32 sum than adding two bf16 tensors is."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd._lib import call, ptr, stream_ptr, dtype_code
+    g = torch.Generator().manual_seed(7 * B + ci)
+    x = torch.randn(B, H, W, ci, generator=g).cuda().bfloat16().permute(0, 3, 1, 2)
+    a = torch.randn(B, H, W, co, generator=g).cuda().bfloat16().permute(0, 3, 1, 2)
+    w = (torch.randn(co, ci, 5, 5, generator=g) * 0.05).cuda()
+    wp = ops.packed_weight(w, 'conv', 'fwd', torch.bfloat16)
+    ref = F.conv2d(x.float().cpu(), w.bfloat16().float().cpu(), None, padding=2) + a.float().cpu()
+    y = ops.empty_nhwc(B, co, H, W, torch.bfloat16, "cuda")
+    call("sdhip_conv2d_fwd_add", ptr(x), ptr(wp), ptr(y), ptr(a), co, B, H, W, ci, ci, H, W, co, co, 5, 5, 2, 2, dtype_code(x), stream_ptr())
+    y2 = a.clone(memory_format=torch.preserve_format)
+    ops._conv_launch(x, ci, wp, y2, co, None, None, None, None, B, H, W, ci, H, W, co, 5, 5, 1, 1, 2, 2, False, 1, 0, True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= 2.0 ** -8 * ref.abs().max().item()          # one bf16 rounding of the sum
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,k,last,H,W", [(64, 64, 5, False, 128, 256), (32, 32, 3, True, 48, 64), (16, 32, 5, True, 128, 192)])
+def test_conv2downup_gradient_slots_match_autograd_adds(cin, cout, k, last, H, W):
+    """Conv2DownUp with the skip gradients summed by the data-gradient launches (ops.GradSlot) against the same block with
+    every skip gradient returned to autograd: same forward, gradients equal up to the one bf16 rounding the fused sum saves."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    torch.manual_seed(3)
+    blk = N.Conv2DownUp(cin, cout, k, lastLayer=last).cuda().train()
+    x = torch.randn(4, H, W, cin, device="cuda").bfloat16().permute(0, 3, 1, 2)
+    gy = torch.randn(4, H, W, cout, device="cuda").bfloat16().permute(0, 3, 1, 2)
+
+    def run(slots):
+        old = N.GRAD_SLOTS
+        N.GRAD_SLOTS = slots
+        try:
+            for p in blk.parameters():
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            y = blk(xi, groups=2)
+            # a consumer that hands the SAME gradient tensor to two inputs (what torch's add does): the block must not write into it
+            z = y + y.detach() * 0.0
+            z.backward(gy)
+            torch.cuda.synchronize()
+            return y.detach().float(), xi.grad.float(), [p.grad.float().clone() for p in blk.parameters() if p.grad is not None]
+        finally:
+            N.GRAD_SLOTS = old
+
+    y1, gx1, gp1 = run(True)
+    y0, gx0, gp0 = run(False)
+    assert torch.equal(y1, y0)
+    assert (gx1 - gx0).abs().max().item() <= 3e-2 * gx0.abs().max().item()
+    for a, b in zip(gp1, gp0):
+        assert (a - b).abs().max().item() <= 3e-2 * b.abs().max().item() + 1e-6

@@ -86,7 +86,9 @@ template <> struct LdsRow<1> {
 // DMA: the halo tile goes global -> LDS by LDS-DMA (no BatchNorm prologue, no odd channel tail); otherwise through
 // registers with the prologue applied on the way.  Two instantiations, so that the DMA variant contains no ordinary
 // global load at all inside its stage loop (hipcc would wait for it — and with it for the DMA — in the MFMA loop).
-template <typename T, int TH, int TW, int BN, int KS, bool DMA>
+// BX: the BatchNorm-backward-sums epilogue (FastArgs::bx) — an instantiation of its own, because its extra live values
+// push the 8x32x64 form from 244 to 264 VGPRs, i.e. from two workgroups per CU to one, for EVERY launch of that form.
+template <typename T, int TH, int TW, int BN, int KS, bool DMA, bool BX = false>
 __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   constexpr int V = Chunk<T>::N;          // elements per 16 bytes
   constexpr int CK = 8 * V;               // channels per packed weight row (always 128 bytes)
@@ -444,8 +446,8 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   // (accumulating launches take the general path: its per-tile branches keep the old values' loads from being hoisted
   //  together, which would cost ~100 VGPRs — a wave of occupancy — in every launch of this kernel)
   const bool interior = oh0 + TH <= p.Ho && ow0 + TW <= p.Wo && n0 + BN <= p.Cout && !p.accumulate;   // wave-uniform
-  if (p.bx) {   // uniform; host: stats set, Cout % 4 == 0, omul == 1, no accumulate / bias / activation
-    if constexpr (sizeof(T) == 2) {   // bf16 only (host-checked)
+  if constexpr (BX) {   // host: bx / stats set, bf16, Cout % 4 == 0, omul == 1, no accumulate / bias / activation
+    {
     const T* const ub = (const T*)p.bx + zimg * p.Ho * p.Wo * p.ldbx;
 #pragma unroll
     for (int mi = 0; mi < NT_CO; ++mi) {
@@ -478,6 +480,8 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
       }
     }
     }
+  }
+  if constexpr (BX) {
   } else if (interior) {
     T* const d0 = yb + ((long)(oh0 + pt0 / TWT) * om * WoD + (ow0 + (pt0 % TWT) * 16 + l15) * om) * p.ldy + n0 + 4 * lg;
 #pragma unroll
@@ -579,9 +583,9 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   }
 }
 
-template <typename T, int TH, int TW, int BN, int KS, bool DMA>
+template <typename T, int TH, int TW, int BN, int KS, bool DMA, bool BX = false>
 int launch_fast(const FastArgs& a, size_t lds, hipStream_t s) {
-  auto kern = conv_fast_kernel<T, TH, TW, BN, KS, DMA>;
+  auto kern = conv_fast_kernel<T, TH, TW, BN, KS, DMA, BX>;
   static bool attr_set = false;  // per instantiation
   if (lds > 64 * 1024 && !attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -610,8 +614,23 @@ int launch_fast_tile(const FastArgs& a, bool big, int ks, int bn, size_t lds, hi
   return ks == 2 ? launch_fast_bn<T, 4, 16, 2, DMA>(a, bn, lds, s) : launch_fast_bn<T, 4, 16, 1, DMA>(a, bn, lds, s);
 }
 
+template <int TH, int TW, int KS>
+int launch_fast_bx_bn(const FastArgs& a, int bn, size_t lds, hipStream_t s) {   // bf16, LDS-DMA halo, BatchNorm-backward sums
+  switch (bn) {
+    case 16: return launch_fast<bf16_t, TH, TW, 16, KS, true, true>(a, lds, s);
+    case 32: return launch_fast<bf16_t, TH, TW, 32, KS, true, true>(a, lds, s);
+    case 64: return launch_fast<bf16_t, TH, TW, 64, KS, true, true>(a, lds, s);
+    default: return launch_fast<bf16_t, TH, TW, 128, KS, true, true>(a, lds, s);
+  }
+}
+
 template <typename T>
 int launch_fast_any(const FastArgs& a, bool big, int ks, int bn, size_t lds, hipStream_t s) {
+  if (a.bx) {
+    if (!a.dma || sizeof(T) != 2) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_bnbwd: bf16 without an input prologue / channel tail only");
+    if (big) return ks == 2 ? launch_fast_bx_bn<8, 32, 2>(a, bn, lds, s) : launch_fast_bx_bn<8, 32, 1>(a, bn, lds, s);
+    return ks == 2 ? launch_fast_bx_bn<4, 16, 2>(a, bn, lds, s) : launch_fast_bx_bn<4, 16, 1>(a, bn, lds, s);
+  }
   return a.dma ? launch_fast_tile<T, true>(a, big, ks, bn, lds, s) : launch_fast_tile<T, false>(a, big, ks, bn, lds, s);
 }
 

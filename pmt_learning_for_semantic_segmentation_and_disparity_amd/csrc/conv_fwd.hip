@@ -490,6 +490,16 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     SDHIP_LAUNCH_CHECK();
     return SDHIP_OK;
   }
+  // ---- one input channel fanned out to <= 64 output channels (conv_thin.h): taps as the MFMA reduction axis ----
+  if (!bx && !addend && omul == 1 && dtype == SDHIP_BF16 && fanout_ok(Cin, Cout, kh * kw, stride, kd, ldy, y) && D == 1 && Do == 1 && !in_scale &&
+      !accumulate && !stats && !bias && act == 0 && (kh - 1) * dil <= 31 && (kw - 1) * dil <= 31 && (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) < (1L << 31) &&
+      B <= 65535 && !dg.conv_no_thin) {
+    FanArgs t;
+    t.x = x; t.wp = wpacked; t.y = y;
+    t.B = B; t.H = H; t.W = W; t.Ho = Ho; t.Wo = Wo; t.kh = kh; t.kw = kw; t.dil = dil; t.pad_t = pad_t; t.pad_l = pad_l;
+    t.ldx = ldx; t.Cout = Cout; t.Mpad = a.Mpad; t.ldy = ldy;
+    return launch_fanout(t, s);
+  }
   // ---- 1x1 as a streaming GEMM (conv_gemm.h): bf16, plain stride-1 1x1 over whole images ----
   if (!bx && !addend && omul == 1 && dtype == SDHIP_BF16 && kh == 1 && kw == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && D == 1 && Do == 1 &&
       Ho == H && Wo == W && !accumulate && !dg.conv_generic && !dg.conv_no_gemm) {
@@ -505,7 +515,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
   }
   // ---- persistent whole-CU kernel (conv_band.h): the full-resolution 5x5 layers, bf16, <= 64 channels either side ----
   if (!bx && omul == 1 && dtype == SDHIP_BF16 && kh == 5 && kw == 5 && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
-      !((accumulate || addend) && stats) && !(accumulate && addend) && (!addend || (ldadd % 8 == 0 && ((uintptr_t)addend & 15) == 0)) && Cin % 8 == 0 && (Cin <= 32 || Cin == 64) && a.Mpad <= 64 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
+      !((accumulate || addend) && stats) && !(accumulate && addend) && (!addend || (ldadd % 8 == 0 && ((uintptr_t)addend & 15) == 0)) && Cin % 8 == 0 && (Cin <= 32 || Cin == 64) && a.Mpad <= 64 && a.Mpad >= 32 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
       (long)B * H * W * ldx * 2 < (long)kBandOob && band_ok(sdhip_cdiv(Ho, 16) * sdhip_cdiv(Wo, 32) * B) && !dg.conv_generic && !dg.conv_no_band) {
     BandArgs f;
     f.x = x; f.wp = wpacked; f.y = y; f.bias = bias; f.stats = stats;

@@ -224,4 +224,93 @@ __global__ __launch_bounds__(256) void conv_thin_wgrad_tiled_kernel(const ThinWg
   if (p.dbias && tid == 0) atomicAdd(p.dbias, bsh);
 }
 
+
+// ---- ONE input channel -> up to 64 output channels, <= 32 taps, stride 1, bf16 --------------------------------------
+// The data gradient of a convolution with a single output map (the disparity head `ConvTranspose2dSame(64, 1, 5)` and the
+// 1x1 attention gates `conv2dSame(64, 1, 1)`, models/dsnet_t2.py: dispoutConv / conv1d_at_*): y[p][m] = sum_t x[p + off_t] *
+// w[m][t].  On the halo-tile kernels the one real channel rides in a 32-channel k-step (1/32 of every MFMA) — 159 us for
+// a layer whose only real work is writing 134 MB.  Here the TAPS are the reduction axis: one v_mfma_f32_16x16x32_bf16
+// per (16 pixels x 16 output channels) with k = tap index; the pixel operand is gathered from a scalar halo tile in LDS.
+struct FanArgs {
+  const void* x; const void* wp; void* y;
+  int B, H, W, Ho, Wo, kh, kw, dil, pad_t, pad_l;
+  int ldx, Cout, Mpad, ldy;
+};
+
+__global__ __launch_bounds__(256) void conv_fanout_kernel(const FanArgs p) {
+  constexpr int TH = 8, TW = 32, CK = 64;
+  __shared__ __attribute__((aligned(16))) bf16_t wl[64][32];      // [output channel][tap], zero beyond the kernel / Cout
+  __shared__ bf16_t xt[(TH + 31) * (TW + 31) + 8];                 // halo tile of the single input map (taps <= 32 => extent <= 31 more)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int Tn = p.kh * p.kw;
+  const int tiles_w = (p.Wo + TW - 1) / TW;
+  const int ty = blockIdx.x / tiles_w, oh0 = ty * TH, ow0 = (blockIdx.x - ty * tiles_w) * TW;
+  const int b = blockIdx.y;
+  const int IH = TH + (p.kh - 1) * p.dil, IW = TW + (p.kw - 1) * p.dil;
+  const bf16_t* xb = (const bf16_t*)p.x + (long)b * p.H * p.W * p.ldx;
+  for (int i = tid; i < 64 * 32; i += 256) {
+    const int m = i >> 5, t = i & 31;
+    wl[m][t] = (m < p.Cout && t < Tn) ? ((const bf16_t*)p.wp)[((long)t * p.Mpad + m) * CK] : (bf16_t)0;   // packed [t][Mpad][64], channel 0
+  }
+  for (int i = tid; i < IH * IW; i += 256) {
+    const int ih = i / IW, iw = i - ih * IW;
+    const int gh = oh0 - p.pad_t + ih, gw = ow0 - p.pad_l + iw;
+    xt[i] = (gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) ? xb[((long)gh * p.W + gw) * p.ldx] : (bf16_t)0;
+  }
+  __syncthreads();
+  // tap t of this lane's k-slice (8 taps: 8*lg .. 8*lg+7): offset inside the halo tile, taps past the kernel read slot 0
+  // (their weights are zero)
+  int toff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int t = 8 * lg + j;
+    const int khi = t / p.kw, kwi = t - khi * p.kw;
+    toff[j] = t < Tn ? khi * p.dil * IW + kwi * p.dil : 0;
+  }
+  u32x4 af[4];                                                     // weights: lane (l15 = output channel of the tile, lg = k-slice)
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const u32x4*>(&wl[mi * 16 + l15][8 * lg]);
+  bf16_t* yb = (bf16_t*)p.y + (long)b * p.Ho * p.Wo * p.ldy;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {                                 // wave: tile rows 2*wave, 2*wave + 1; two 16-pixel column blocks each
+    const int r = 2 * wave + (ni >> 1), c = (ni & 1) * 16 + l15;
+    const int base = r * IW + c;
+    unsigned short v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = xt[base + toff[j]];
+    const u32x4 bfrag = u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                              (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+    const int oh = oh0 + r, ow = ow0 + c;
+    const bool valid = oh < p.Ho && ow < p.Wo;
+    bf16_t* dst = yb + ((long)oh * p.Wo + ow) * p.ldy;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      if (mi * 16 < p.Mpad) {                                      // uniform
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        Mma<bf16_t>::run(acc, af[mi], bfrag);
+        const int co = mi * 16 + 4 * lg;
+        if (valid && co + 3 < p.Cout) {
+          *reinterpret_cast<u32x2*>(dst + co) = u32x2{pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3])};
+        } else if (valid) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.Cout) dst[co + e] = f2bf(acc[e]);
+        }
+      }
+    }
+  }
+}
+
+inline bool fanout_ok(int Cin, int Cout, int T, int stride, int kd, int ldy, const void* y) {
+  return Cin == 1 && Cout <= 64 && Cout >= 8 && T <= 32 && stride == 1 && kd == 1 && ldy % 4 == 0 && ((uintptr_t)y & 7) == 0;
+}
+
+inline int launch_fanout(const FanArgs& a, hipStream_t s) {
+  dim3 grid(sdhip_cdiv(a.Ho, 8) * sdhip_cdiv(a.Wo, 32), a.B);
+  hipLaunchKernelGGL(conv_fanout_kernel, grid, dim3(256), 0, s, a);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
 }  // namespace

@@ -240,6 +240,9 @@ class _Stem(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, bn, groups):
+        # an output nobody consumes (tap 0 in the configurations without the full-resolution pyramid) must not come back as a
+        # materialised NCHW zero tensor: that is a fill, a layout conversion and an add over 67 MB for nothing
+        ctx.set_materialize_grads(False)
         B, Cin, H, W = x.shape
         xv, ldx = ops.nhwc_view(x)
         if weight.shape[-1] == 4:
@@ -270,15 +273,20 @@ class _Stem(torch.autograd.Function):
         npix = B * spec.Ho * spec.Wo
         dt = dtype_code(xv)
         # gradient w.r.t. the raw conv output = tap-0 consumers + the norm0/relu branch
+        if g0 is None and gf is None:
+            return None, None, None, None, None, None
         graw = ops.empty_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
-        gv, ldg = ops.nhwc_view(g0)
-        call("sdhip_affine_act", ptr(gv), ldg, ptr(graw), Cout, None, 0, None, None, npix, Cout, 1, 0, dt, stream_ptr())
-        fv, ldf = ops.nhwc_view(gf)
-        dgamma, dbeta, dS = ops._bn_backward(fv, ldf, c0, Cout, graw, Cout, scale, shift, mean, invstd, gamma, npix, Cout,
-                                             groups, 1, count, train, dt, accumulate_gx=True, beta=beta)
-        if train:
-            call("sdhip_stats_fix", ptr(graw), Cout, ptr(c0), Cout, ptr(graw), Cout, ptr(dS), Cout, npix, Cout, groups, dt,
-                 stream_ptr())
+        if g0 is not None:
+            gv, ldg = ops.nhwc_view(g0)
+            call("sdhip_affine_act", ptr(gv), ldg, ptr(graw), Cout, None, 0, None, None, npix, Cout, 1, 0, dt, stream_ptr())
+        dgamma = dbeta = None
+        if gf is not None:
+            fv, ldf = ops.nhwc_view(gf)
+            dgamma, dbeta, dS = ops._bn_backward(fv, ldf, c0, Cout, graw, Cout, scale, shift, mean, invstd, gamma, npix, Cout,
+                                                 groups, 1, count, train, dt, accumulate_gx=g0 is not None, beta=beta)
+            if train:
+                call("sdhip_stats_fix", ptr(graw), Cout, ptr(c0), Cout, ptr(graw), Cout, ptr(dS), Cout, npix, Cout, groups, dt,
+                     stream_ptr())
         _, gw, _ = ops._conv_backward(spec, xv, ldx, weight, graw, Cout, None, None, False, 1, False, True)
         return None, gw, dgamma, dbeta, None, None
 

@@ -1024,6 +1024,7 @@ class _SplitBatchFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, B):
+        ctx.set_materialize_grads(False)          # an unused half arrives as None (zeroed below), not as an NCHW zero tensor
         ctx.B = B
         ctx.meta = (tuple(x.shape), x.dtype, x.device)
         return x[:B], x[B:]
@@ -1032,6 +1033,8 @@ class _SplitBatchFn(torch.autograd.Function):
     def backward(ctx, ga, gb):
         (N, C, H, W), dtype, dev = ctx.meta
         B = ctx.B
+        if ga is None and gb is None:
+            return None, None
         g, ld = alloc_nhwc(N, C, H, W, dtype, dev)
         for part, lo, hi in ((ga, 0, B), (gb, B, N)):
             dst = g[lo:hi]

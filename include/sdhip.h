@@ -143,10 +143,12 @@ int sdhip_conv2d_fwd_add(const void* x, const void* wpacked, void* y, const void
  *     sums[rep][g][0][c] += sum_pixels gm * u,   sums[rep][g][1][c] += sum_pixels gm,
  *     gm = y where u*scale[g][c] + shift[g][c] > 0, else 0
  * (f64 [sums_nrep][groups][2][sums_ld >= Cout], zeroed by the caller) — what sdhip_affine_act_bwd computes in a pass of its
- * own over y and u.  u: [B][Ho][Wo] pixels of ldu elements, Cout of them used.  bf16, Cout % 4 == 0; consumer:
- * sdhip_bn_bwd_apply_fin_d. */
+ * own over y and u.  u: [B][Ho][Wo] pixels of ldu elements, Cout of them used.  addend (optional, as sdhip_conv2d_fwd_add):
+ * y = conv + addend, sums taken over that total — the convbn + ReLU layers of Conv2DownUp (models/dsnet_t2.py:80-117), whose
+ * output gradient is the next layer's data gradient plus a skip gradient.  bf16, Cout % 4 == 0; consumer:
+ * sdhip_bn_bwd_apply_fin_d.  SDHIP_ERR_UNSUPPORTED when the shape has no kernel with this epilogue. */
 int sdhip_conv2d_fwd_bnbwd(const void* x, const void* wpacked, void* y, double* sums, int sums_ld, int sums_nrep,
-                           const void* u, int ldu, const float* scale, const float* shift,
+                           const void* u, int ldu, const float* scale, const float* shift, const void* addend, int ldadd,
                            int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,
                            int kh, int kw, int dil, int pad_t, int pad_l, int groups, int dtype, void* stream);
 

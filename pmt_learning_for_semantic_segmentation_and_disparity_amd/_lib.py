@@ -89,7 +89,7 @@ SIGNATURES = {
     "sdhip_bn_bwd_apply_fin": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _d, _i, _i, _p],
     "sdhip_bn_bwd_apply_fin_d": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _d, _i, _i, _p],
     "sdhip_conv2d_fwd_add": [_p, _p, _p, _p, _i] + [_i] * 14 + [_p],
-    "sdhip_conv2d_fwd_bnbwd": [_p, _p, _p, _p, _i, _i, _p, _i, _p, _p] + [_i] * 16 + [_p],
+    "sdhip_conv2d_fwd_bnbwd": [_p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _i] + [_i] * 16 + [_p],
 }
 _lib.sdhip_lovasz_workspace_bytes.argtypes = [_l, _i]
 _lib.sdhip_lovasz_workspace_bytes.restype = _l
@@ -141,6 +141,7 @@ def _diag_switch(name):
 DIAG_NO_FUSED_BN = bool(_diag_switch("SDHIP_DIAG_NO_FUSED_BN"))
 DIAG_NO_SIDE = bool(_diag_switch("SDHIP_DIAG_NO_SIDE"))
 DIAG_NO_GRAD_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_GRAD_SLOTS"))
+DIAG_NO_BN_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_BN_SLOTS"))
 DIAG_NO_BNBWD_EPILOGUE = bool(_diag_switch("SDHIP_DIAG_NO_BNBWD_EPILOGUE"))
 DIAG_STEM_S2D = _diag_switch("SDHIP_STEM_S2D")
 

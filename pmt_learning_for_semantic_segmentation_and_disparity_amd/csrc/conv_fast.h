@@ -39,6 +39,7 @@ struct FastArgs {
   // receive sum(gm * u) and sum(gm), gm = g where z > 0 else 0 — the reductions of sdhip_affine_act_bwd — instead of
   // sum(y), sum(y^2).  nullptr: plain statistics.
   const void* bx; const float* bsc; const float* bsh; int ldbx;
+  const void* res; int ldres;   // BX launches only: y = result + res (a second gradient contribution, same geometry as y)
 };
 
 // source of every padding / dead lane of an LDS-DMA load
@@ -449,6 +450,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   if constexpr (BX) {   // host: bx / stats set, bf16, Cout % 4 == 0, omul == 1, no accumulate / bias / activation
     {
     const T* const ub = (const T*)p.bx + zimg * p.Ho * p.Wo * p.ldbx;
+    const T* const rb = (const T*)p.res + zimg * p.Ho * p.Wo * p.ldres;
 #pragma unroll
     for (int mi = 0; mi < NT_CO; ++mi) {
       const int co = n0 + mi * 16 + 4 * lg;
@@ -465,7 +467,11 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
         if (cok && oh < p.Ho && ow < p.Wo) {
           const long pix = (long)oh * p.Wo + ow;
           const u32x2 uu = *reinterpret_cast<const u32x2*>(ub + pix * p.ldbx + co);
-          const f32x4 v = acc[mi][ni];
+          f32x4 v = acc[mi][ni];
+          if (p.res) {                          // uniform
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(rb + pix * p.ldres + co);
+            v += f32x4{bflo(rr[0]), bfhi(rr[0]), bflo(rr[1]), bfhi(rr[1])};
+          }
           const u32x2 o = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
           *reinterpret_cast<u32x2*>(yb + pix * p.ldy + co) = o;
           const float g4[4] = {bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1])};

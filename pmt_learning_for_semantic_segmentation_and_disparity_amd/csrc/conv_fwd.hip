@@ -514,8 +514,8 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     if (gemm1x1_ok(g, (in_scale || stats) ? groups : 1)) return launch_gemm_any(g, s);
   }
   // ---- persistent whole-CU kernel (conv_band.h): the full-resolution 5x5 layers, bf16, <= 64 channels either side ----
-  if (!bx && omul == 1 && dtype == SDHIP_BF16 && kh == 5 && kw == 5 && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
-      !((accumulate || addend) && stats) && !(accumulate && addend) && (!addend || (ldadd % 8 == 0 && ((uintptr_t)addend & 15) == 0)) && Cin % 8 == 0 && (Cin <= 32 || Cin == 64) && a.Mpad <= 64 && a.Mpad >= 32 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
+  if ((!bx || (stats && Cout % 8 == 0 && ldbx % 8 == 0 && ((uintptr_t)bx & 15) == 0 && !bias && act == 0)) && omul == 1 && dtype == SDHIP_BF16 && kh == 5 && kw == 5 && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
+      (bx || !((accumulate || addend) && stats)) && !(accumulate && addend) && (!addend || (ldadd % 8 == 0 && ((uintptr_t)addend & 15) == 0)) && Cin % 8 == 0 && (Cin <= 32 || Cin == 64) && a.Mpad <= 64 && a.Mpad >= 32 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
       (long)B * H * W * ldx * 2 < (long)kBandOob && band_ok(sdhip_cdiv(Ho, 16) * sdhip_cdiv(Wo, 32) * B) && !dg.conv_generic && !dg.conv_no_band) {
     BandArgs f;
     f.x = x; f.wp = wpacked; f.y = y; f.bias = bias; f.stats = stats;
@@ -523,9 +523,10 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     f.Cin = Cin; f.ldx = ldx; f.Cout = Cout; f.Mpad = a.Mpad; f.ldy = ldy;
     f.bpg = B / groups; f.act = act; f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride;
     f.res = addend ? addend : (accumulate ? y : nullptr); f.ldres = addend ? ldadd : ldy;
+    f.bx = bx; f.ldbx = ldbx; f.bsc = bsc; f.bsh = bsh;
     return launch_band<5>(f, s);
   }
-  if (addend) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_add: only the persistent 5x5 kernel adds a second tensor in its epilogue (bf16, <= 64 channels, >= 192 tiles of 16x32)");
+  if (addend && !bx) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_add: only the persistent 5x5 kernel adds a second tensor in its epilogue (bf16, <= 64 channels, >= 192 tiles of 16x32)");
   // ---- fast path (conv_fast.h): 16-byte-aligned pixels on both sides, halo-tile mode ----
   if (!per_tap_any && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && a.vec_out &&
       (long)H * W * ldx < (1L << 31) && !dg.conv_generic) {
@@ -540,6 +541,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride; f.tail = (Cin % V) != 0;
     f.omul = omul; f.ooz = ooz; f.ooy = ooy; f.oox = oox;
     f.bx = bx; f.ldbx = ldbx; f.bsc = bsc; f.bsh = bsh;
+    f.res = bx ? addend : nullptr; f.ldres = ldadd;
     f.dma = !in_scale && !f.tail;
     bool fbig = big;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -646,15 +648,17 @@ extern "C" int sdhip_conv2d_fwd_add(const void* x, const void* wpacked, void* y,
 // Data gradient of a stride-1 convolution whose input was relu(BatchNorm(u)): y = the gradient w.r.t. that input, and the
 // epilogue also takes the two reductions of the BatchNorm backward over it (see include/sdhip.h).
 extern "C" int sdhip_conv2d_fwd_bnbwd(const void* x, const void* wpacked, void* y, double* sums, int sums_ld, int sums_nrep,
-                                      const void* u, int ldu, const float* scale, const float* shift,
+                                      const void* u, int ldu, const float* scale, const float* shift, const void* addend, int ldadd,
                                       int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,
                                       int kh, int kw, int dil, int pad_t, int pad_l, int groups, int dtype, void* stream) {
   SDHIP_CHECK_ARG(dtype == SDHIP_BF16, "conv2d_fwd_bnbwd: bf16 only");
   SDHIP_CHECK_ARG(sums && u && scale && shift && ldu >= Cout && Cout % 4 == 0 && ldu % 4 == 0 && ((uintptr_t)u & 7) == 0 &&
                   ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
                   "conv2d_fwd_bnbwd: sums / u / scale / shift missing or misaligned (Cout %% 4, ldu %% 4)");
+  SDHIP_CHECK_ARG(!addend || (ldadd >= Cout && ldadd % 4 == 0 && ((uintptr_t)addend & 7) == 0), "conv2d_fwd_bnbwd: addend misaligned");
   return conv2d_fwd_impl(x, wpacked, y, nullptr, nullptr, nullptr, sums, sums_ld, sums_nrep, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy,
-                         kh, kw, 1, dil, pad_t, pad_l, 1, 1, 1, 1, 0, 0, groups, 0, 0, dtype, stream, 1, 0, 0, 0, u, ldu, scale, shift);
+                         kh, kw, 1, dil, pad_t, pad_l, 1, 1, 1, 1, 0, 0, groups, 0, 0, dtype, stream, 1, 0, 0, 0, u, ldu, scale, shift,
+                         addend, ldadd);
 }
 
 // One sub-pixel phase of a stride-2 transposed convolution (see include/sdhip.h): a stride-1 correlation whose outputs are

@@ -159,7 +159,7 @@ class _DenseBlockFn(torch.autograd.Function):
                 # ... whose epilogue also takes norm2's two backward reductions (no pass of its own over gp2 and y1)
                 sums2 = ops._zeros((NREP, groups, 2, mid), torch.float64, dev)[0]
                 call("sdhip_conv2d_fwd_bnbwd", ptr(dy2), ptr(wd2), ptr(gp2), ptr(sums2), mid, NREP, ptr(y1), mid,
-                     ptr(sc2), ptr(sh2), B, H, W, growth, growth, H, W, mid, mid, 3, 3, 1, 1, 1, groups, dt, st)
+                     ptr(sc2), ptr(sh2), None, 0, B, H, W, growth, growth, H, W, mid, mid, 3, 3, 1, 1, 1, groups, dt, st)
             else:
                 ops._conv_launch(dy2, growth, wd2, gp2, mid, None, None, None, None, B, H, W, growth, H, W, mid, 3, 3, 1, 1, 1, 1,
                                  False, 1, 0, False)

@@ -109,8 +109,8 @@ class ConvTranspose2dSame(nn.Module):
     def run_bn(self, x, bn, act=0, residual=None, groups=1, **slots):
         c = self.ct2d
         if c.stride[0] != 1:
-            if slots.get("in_slot") is not None or slots.get("res_slot") is not None:
-                raise NotImplementedError("gradient slots are wired for the stride-1 blocks only")
+            if any(v is not None for v in slots.values()):
+                raise NotImplementedError("gradient / BatchNorm slots are wired for the stride-1 blocks only")
             return ops.deconv2d_strided(x, c.weight, None, c.stride[0], bn=bn, act=act, residual=residual, groups=groups)
         return ops.conv_bn_act(x, c.weight, bn, act=act, residual=residual, groups=groups, **slots, **self._geom())
 
@@ -154,17 +154,18 @@ def _act_block(block, p=0.0):
     return nn.Sequential(block, nn.ReLU(inplace=True), nn.Dropout(p=p))
 
 
-def run_act_block(seq, x, residual=None, groups=1, in_slot=None, res_slot=None):
+def run_act_block(seq, x, residual=None, groups=1, **slots):
     """Sequential(convbn|deconvbn, ReLU[, Dropout]) as one fused conv+BN+ReLU(+skip).  With Dropout(p > 0) in training
     mode (models/dsnet_t2.py:85-93; the shipped recipe has p = 0) the mask sits between the ReLU and the skip add, so the
     skip is added after the dropout kernel instead of inside the BatchNorm pass."""
     if len(seq) > 2 and seq[2].p and seq[2].training:
         y = ops.dropout(seq[0].fused(x, act=1, groups=groups), seq[2].p, True, _dropout_id(seq[2]))
         return y if residual is None else ops.add(y, residual)
-    return seq[0].fused(x, act=1, residual=residual, groups=groups, in_slot=in_slot, res_slot=res_slot)
+    return seq[0].fused(x, act=1, residual=residual, groups=groups, **slots)
 
 
-GRAD_SLOTS = not ops._lib.DIAG_NO_GRAD_SLOTS    # tests / diagnostics (SDHIP_DIAG_NO_GRAD_SLOTS): False hands every skip gradient back to autograd (one elementwise add each)
+GRAD_SLOTS = not ops._lib.DIAG_NO_GRAD_SLOTS    # tests / diagnostics (SDHIP_DIAG_NO_GRAD_SLOTS)
+BN_SLOTS = not ops._lib.DIAG_NO_BN_SLOTS        # ... (SDHIP_DIAG_NO_BN_SLOTS): BatchNorm backward reductions in the consumer's data gradient: False hands every skip gradient back to autograd (one elementwise add each)
 
 
 class Conv2DownUp(nn.Module):
@@ -191,12 +192,15 @@ class Conv2DownUp(nn.Module):
         # of the network hands in, which is only read
         s1 = ops.GradSlot(exclusive=self.lastLayer) if slotted else None
         s2 = ops.GradSlot(exclusive=True) if slotted else None
-        x1 = run_act_block(self.c1, x, groups=groups)
-        x2 = run_act_block(self.c2, x1, groups=groups, in_slot=s1)
-        x = run_act_block(self.c3, x2, groups=groups, in_slot=s2)
-        x = run_act_block(self.d3, x, residual=x2, groups=groups, res_slot=s2)
-        x = run_act_block(self.d4, x, residual=x1, groups=groups, res_slot=s1)
-        return run_act_block(self.d5, x, groups=groups) if self.lastLayer else x
+        # every layer's output has exactly one consumer inside the block (plus the slotted skips): that consumer's data
+        # gradient takes the reductions of the layer's BatchNorm backward (ops.BNSlot)
+        b = [ops.BNSlot() if slotted and BN_SLOTS else None for _ in range(5)]
+        x1 = run_act_block(self.c1, x, groups=groups, out_bn=b[0])
+        x2 = run_act_block(self.c2, x1, groups=groups, in_slot=s1, in_bn=b[0], out_bn=b[1])
+        x = run_act_block(self.c3, x2, groups=groups, in_slot=s2, in_bn=b[1], out_bn=b[2])
+        x = run_act_block(self.d3, x, residual=x2, groups=groups, res_slot=s2, in_bn=b[2], out_bn=b[3])
+        x = run_act_block(self.d4, x, residual=x1, groups=groups, res_slot=s1, in_bn=b[3], out_bn=b[4] if self.lastLayer else None)
+        return run_act_block(self.d5, x, groups=groups, in_bn=b[4]) if self.lastLayer else x
 
 
 # --------------------------------------------------------------------------- pyramids, heads, full network

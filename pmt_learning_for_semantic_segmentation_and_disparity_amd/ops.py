@@ -443,8 +443,26 @@ class GradSlot:
         self.exclusive = exclusive
 
 
+BN_SLOT_MAX_BYTES = 40 << 20
+
+
+class BNSlot:
+    """Links a convbn + ReLU node to the ONE node that consumes its output, so that the consumer's data-gradient launch —
+    which holds every value of dL/d relu(bn(u)) once — also takes the two reductions the BatchNorm backward starts with
+    (sdhip_conv2d_fwd_bnbwd) and the producer's backward skips its reduction pass over that gradient and u.
+    The producer fills (u, scale, shift) in its forward; the consumer's backward fills (sums, gptr); the producer uses the
+    sums only if the gradient it is handed IS the tensor the consumer wrote (gptr) — any other gradient route (an extra
+    consumer, autograd summing contributions) silently falls back to the two-pass form."""
+    __slots__ = ("u", "ldu", "scale", "shift", "groups", "C", "sums", "gptr")
+
+    def __init__(self):
+        self.u = self.scale = self.shift = self.sums = None
+        self.ldu = self.groups = self.C = 0
+        self.gptr = 0
+
+
 def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_relu, groups, need_x, need_w, bias=None, acc_into=None,
-                   addend=None):
+                   addend=None, bn_slot=None):
     has_bias = bias is not None
     """dgrad (w.r.t. the post-prologue input) and wgrad of one conv; returns (g_post, gw, gb)."""
     spec = ctx_spec
@@ -455,7 +473,32 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
     gpost = gw = gb = None
     if need_x:
         wd = packed_weight(weight, spec.kind, 'dgrad', xv.dtype)
-        if acc_into is not None:
+        fused_bn = False
+        # Measured (profiles/r02_step_summary.txt): the epilogue's reads of u sit exposed behind the MFMA loop, so on maps
+        # of more than ~40 MB (and in the one-workgroup-per-CU 5x5 kernel at any size) it costs more than the streaming
+        # pass it replaces (full resolution, 32 channels: +33 us against a 27 us pass; 5x5 / 64 channels: +126 against 60);
+        # below that the pass is launch- and latency-bound and the fusion wins (64 channels at 128x256: +3.5 against 18)
+        if (bn_slot is not None and bn_slot.u is not None and bn_slot.C == Cin and xv.dtype == torch.bfloat16 and spec.stride == 1
+                and spec.sd == 1 and spec.kd == 1 and spec.D == 1 and tuple(bn_slot.u.shape) == (Bimg, Cin, H, W)
+                and spec.kh * spec.kw <= 9 and Bimg * H * W * Cin * 2 <= BN_SLOT_MAX_BYTES):
+            # the input of this convolution was relu(bn(u)): the launch that writes its gradient also takes that
+            # BatchNorm's two backward reductions (and adds a parked skip gradient on the way)
+            other = acc_into if acc_into is not None else addend
+            gpost, ldgp = alloc_nhwc(Bimg, Cin, H, W, xv.dtype, xv.device)
+            sums = _zeros((NREP, bn_slot.groups, 2, Cin), torch.float64, xv.device)[0]
+            ov, ldo = nhwc_view(other) if other is not None else (None, 0)
+            rc = _lib._lib.sdhip_conv2d_fwd_bnbwd(ptr(g), ptr(wd), ptr(gpost), ptr(sums), Cin, NREP, ptr(bn_slot.u), bn_slot.ldu,
+                                                  ptr(bn_slot.scale), ptr(bn_slot.shift), ptr(ov), ldo, B, spec.Ho, spec.Wo, Cout, ldg,
+                                                  H, W, Cin, ldgp, spec.kh, spec.kw, spec.dil, spec.dil * (spec.kh - 1) - spec.pad_t,
+                                                  spec.dil * (spec.kw - 1) - spec.pad_l, bn_slot.groups, dtype_code(xv), stream_ptr())
+            if rc == 0:
+                bn_slot.sums, bn_slot.gptr = sums, gpost.data_ptr()
+                fused_bn = True
+            elif rc != _lib.ERR_UNSUPPORTED:
+                raise _lib.SdhipError("sdhip_conv2d_fwd_bnbwd failed (%d): %s" % (rc, _lib._lib.sdhip_last_error().decode()))
+        if fused_bn:
+            pass
+        elif acc_into is not None:
             gpost, ldgp = nhwc_view(acc_into)     # holds the other contribution: this launch adds to it
         else:
             gpost, ldgp = alloc_nhwc(Bimg, Cin, H, W, xv.dtype, xv.device)
@@ -470,8 +513,8 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
             call("sdhip_stuff", ptr(g), ldg, ptr(gsrc), Cout, B, spec.Do, spec.Ho, spec.Wo, Cout, spec.sd, spec.stride, 1, dt,
                  stream_ptr())
             ldsrc = Cout
-        fused_add = False
-        if addend is not None and spec.kd == 1 and spec.D == 1 and spec.dil == 1 and gsrc is g:
+        fused_add = fused_bn
+        if not fused_bn and addend is not None and spec.kd == 1 and spec.D == 1 and spec.dil == 1 and gsrc is g:
             av, lda = nhwc_view(addend)
             rc = _lib._lib.sdhip_conv2d_fwd_add(ptr(gsrc), ptr(wd), ptr(gpost), ptr(av), lda, B, Hg, Wg, Cout, ldsrc, H, W, Cin, ldgp,
                                                 spec.kh, spec.kw, pt, pl, dtype_code(xv), stream_ptr())
@@ -483,6 +526,7 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
                          spec.kh, spec.kw, 1, spec.dil, pt, pl, False, 1, 0, acc_into is not None, 1, (Dg, spec.D, spec.kd, 1, pd))
             if addend is not None:            # no kernel on this shape's path adds a second tensor: one elementwise pass
                 gpost = add(gpost, addend)
+
     if need_w:
         gw, gb = wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu, groups)
     return gpost, gw, gb
@@ -590,9 +634,9 @@ class _ConvBNActFn(torch.autograd.Function):
     normalises, activates and adds the skip.  convbn / deconvbn (+ReLU, + skip add) of models/dsnet_t2.py:16-117."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, spec, bn, act, groups, in_slot=None, res_slot=None):
+    def forward(ctx, x, weight, gamma, beta, residual, spec, bn, act, groups, in_slot=None, res_slot=None, in_bn=None, out_bn=None):
         _require_gpu(x, weight)
-        ctx.in_slot, ctx.res_slot = in_slot, res_slot
+        ctx.in_slot, ctx.res_slot, ctx.in_bn, ctx.out_bn = in_slot, res_slot, in_bn, out_bn
         Bimg, Cin, H, W = x.shape
         Btrue = Bimg // spec.D
         B = Btrue * spec.Do                      # output images
@@ -622,6 +666,8 @@ class _ConvBNActFn(torch.autograd.Function):
         ctx.spec, ctx.act, ctx.groups, ctx.ldx, ctx.count, ctx.train = spec, act, groups, ldx, count, train
         ctx.ldraw = ldr_
         ctx.has_res = residual is not None
+        if out_bn is not None and train and act == 1 and _fused_bn() and spec.D == 1 and spec.Do == 1:
+            out_bn.u, out_bn.ldu, out_bn.scale, out_bn.shift, out_bn.groups, out_bn.C = yraw, ldr_, scale, shift, groups, Cout
         ctx.save_for_backward(xv, weight, gamma, beta, yraw, scale, shift, mean, invstd)
         return y
 
@@ -636,7 +682,20 @@ class _ConvBNActFn(torch.autograd.Function):
         g, ldg = nhwc_view(gy)
         graw, ldgr = alloc_nhwc(B, Cout, spec.Ho, spec.Wo, xv.dtype, xv.device)
         ldraw = ctx.ldraw
-        if ctx.train and ctx.act in (0, 1, 2) and _fused_bn():
+        ob = ctx.out_bn
+        if ob is not None and ob.sums is not None and ob.gptr == g.data_ptr() and ctx.train and _fused_bn():
+            # the node that produced gy already summed it against yraw (BNSlot): straight to the second phase
+            tg, tb = _grad_target(gamma), _grad_target(beta)
+            direct = tg is not None and tb is not None
+            dgamma = tg if direct else torch.empty(Cout, dtype=torch.float32, device=xv.device)
+            dbeta = tb if direct else torch.empty(Cout, dtype=torch.float32, device=xv.device)
+            call("sdhip_bn_bwd_apply_fin_d", ptr(g), ldg, ptr(yraw), ldraw, ptr(graw), ldgr, ptr(scale), ptr(shift), ptr(ob.sums), NREP,
+                 ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), int(direct), npix, Cout, groups, float(ctx.count),
+                 ctx.act, dt, stream_ptr())
+            if direct:
+                dgamma = dbeta = None
+            ob.sums, ob.gptr = None, 0
+        elif ctx.train and ctx.act in (0, 1, 2) and _fused_bn():
             dgamma, dbeta = bn_backward_two_phase(g, ldg, yraw, ldraw, graw, ldgr, scale, shift, mean, invstd, gamma, beta, npix,
                                                   Cout, groups, ctx.act, ctx.count, dt)
         elif ctx.train and ctx.act in (0, 1, 2):
@@ -659,11 +718,11 @@ class _ConvBNActFn(torch.autograd.Function):
             else:
                 addend = parked
         gx, gw, _ = _conv_backward(spec, xv, ctx.ldx, weight, graw, ldgr, None, None, False, 1, ctx.needs_input_grad[0],
-                                   ctx.needs_input_grad[1], acc_into=acc, addend=addend)
+                                   ctx.needs_input_grad[1], acc_into=acc, addend=addend, bn_slot=ctx.in_bn)
         gres = gy if ctx.has_res else None
         if gres is not None and ctx.res_slot is not None:
             ctx.res_slot.g, gres = gy, None                   # handed to the producer-side consumer of the skip tensor instead
-        return gx, gw, dgamma, dbeta, gres, None, None, None, None, None, None
+        return gx, gw, dgamma, dbeta, gres, None, None, None, None, None, None, None, None
 
 
 class _BNConvFn(torch.autograd.Function):
@@ -861,11 +920,13 @@ def conv2d(x, weight, bias=None, *, kind='conv', stride=1, dilation=1, padding=0
 
 
 def conv_bn_act(x, weight, bn, *, kind='conv', stride=1, dilation=1, padding=0, act=0, residual=None, groups=1,
-                in_slot=None, res_slot=None):
+                in_slot=None, res_slot=None, in_bn=None, out_bn=None):
     """in_slot / res_slot (GradSlot, optional): the gradient of `residual` is parked in res_slot instead of being returned
-    to autograd, and a gradient parked in in_slot is summed into this node's data gradient by its own launch."""
+    to autograd, and a gradient parked in in_slot is summed into this node's data gradient by its own launch.
+    in_bn / out_bn (BNSlot, optional): x is the output of the convbn + ReLU node that owns in_bn / this node's output has
+    exactly one consumer, which holds out_bn as its in_bn."""
     return _ConvBNActFn.apply(x, weight, bn.weight, bn.bias, residual, conv_spec(x, weight, kind, stride, dilation, padding),
-                              bn, act, groups, in_slot, res_slot)
+                              bn, act, groups, in_slot, res_slot, in_bn, out_bn)
 
 
 def bn_conv(x, stats, bn, weight, *, padding=0, groups=1):

@@ -175,3 +175,46 @@ def test_conv2downup_gradient_slots_match_autograd_adds(cin, cout, k, last, H, W
     assert (gx1 - gx0).abs().max().item() <= 3e-2 * gx0.abs().max().item()
     for a, b in zip(gp1, gp0):
         assert (a - b).abs().max().item() <= 3e-2 * b.abs().max().item() + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,B,ci,co,H,W,groups,with_add", [
+    (5, 4, 64, 64, 96, 256, 2, False), (5, 4, 64, 64, 100, 250, 2, True), (5, 4, 32, 32, 96, 256, 1, True),
+    (3, 4, 64, 64, 48, 64, 2, True), (3, 2, 32, 128, 33, 47, 1, True)])
+def test_data_gradient_with_bn_sums_and_addend(k, B, ci, co, H, W, groups, with_add):
+    """sdhip_conv2d_fwd_bnbwd on the band kernel (5x5) and on the halo-tile kernel (3x3), with and without a second
+    gradient contribution: y = conv (+ addend) equals the separate launches, and the two sums equal sdhip_affine_act_bwd's
+    over that y."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd._lib import call, ptr, stream_ptr, dtype_code
+    dev = "cuda"
+    g = torch.Generator().manual_seed(k * 1000 + H)
+    x = torch.randn(B, H, W, ci, generator=g).to(dev).bfloat16().permute(0, 3, 1, 2)
+    u = torch.randn(B, H, W, co, generator=g).to(dev).bfloat16().permute(0, 3, 1, 2)
+    a = torch.randn(B, H, W, co, generator=g).to(dev).bfloat16().permute(0, 3, 1, 2) if with_add else None
+    w = (torch.randn(co, ci, k, k, generator=g) * 0.05).to(dev)
+    sc = (torch.rand(groups, co, generator=g) + 0.5).to(dev)
+    sh = (torch.randn(groups, co, generator=g) * 0.3).to(dev)
+    wp = ops.packed_weight(w, 'conv', 'fwd', torch.bfloat16)
+    dt = dtype_code(x)
+    pad = k // 2
+    # reference: plain launch (+ f32 add of the second tensor, rounded once), then the reduction pass
+    y0 = ops.empty_nhwc(B, co, H, W, torch.bfloat16, dev)
+    ops._conv_launch(x, ci, wp, y0, co, None, None, None, None, B, H, W, ci, H, W, co, k, k, 1, 1, pad, pad, False, 1, 0, False)
+    y1 = ops.empty_nhwc(B, co, H, W, torch.bfloat16, dev)
+    sums = torch.zeros(ops.NREP, groups, 2, co, dtype=torch.float64, device=dev)
+    call("sdhip_conv2d_fwd_bnbwd", ptr(x), ptr(wp), ptr(y1), ptr(sums), co, ops.NREP, ptr(u), co, ptr(sc), ptr(sh),
+         ptr(a) if with_add else None, co if with_add else 0, B, H, W, ci, ci, H, W, co, co, k, k, 1, pad, pad, groups, dt, stream_ptr())
+    torch.cuda.synchronize()
+    if with_add:
+        ref = F.conv2d(x.float().cpu(), w.bfloat16().float().cpu(), None, padding=pad) + a.float().cpu()
+        assert (y1.float().cpu() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
+    else:
+        assert torch.equal(y0, y1)
+    both = torch.zeros(2, ops.NREP, groups, co, dtype=torch.float32, device=dev)
+    call("sdhip_affine_act_bwd", ptr(y1), co, ptr(u), co, None, 0, ptr(sc), ptr(sh), ptr(both[0]), ptr(both[1]), ops.NREP,
+         B * H * W, co, groups, 1, 0, 0, dt, stream_ptr())
+    torch.cuda.synchronize()
+    ref_s = both.double().sum(1)                  # [2][groups][C]
+    got = sums.sum(0).permute(1, 0, 2)
+    assert (ref_s - got).abs().max().item() <= 3e-4 * ref_s.abs().max().item()

@@ -276,7 +276,7 @@ def test_hip_dgrad_with_bn_backward_sums(B, H, W, Cin, Cout, groups):
          B * H * W, Cout, groups, 1, 0, 0, dt, stream_ptr())
     y1 = ops.empty_nhwc(B, Cout, H, W, torch.bfloat16, dev)
     sums = torch.zeros(ops.NREP, groups, 2, Cout, dtype=torch.float64, device=dev)
-    call("sdhip_conv2d_fwd_bnbwd", ptr(x), ptr(wd), ptr(y1), ptr(sums), Cout, ops.NREP, ptr(u), Cout, ptr(sc), ptr(sh),
+    call("sdhip_conv2d_fwd_bnbwd", ptr(x), ptr(wd), ptr(y1), ptr(sums), Cout, ops.NREP, ptr(u), Cout, ptr(sc), ptr(sh), None, 0,
          B, H, W, Cin, Cin, H, W, Cout, Cout, 3, 3, 1, 1, 1, groups, dt, stream_ptr())
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)

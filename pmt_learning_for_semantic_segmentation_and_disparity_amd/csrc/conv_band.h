@@ -34,8 +34,6 @@ struct BandArgs {
   int Cin, ldx, Cout, Mpad, ldy;
   int bpg, act, stats_ld, nrep;
   const void* res; int ldres;              // y = result + res (same geometry as y; res == y: accumulate in place); nullptr: off
-  // BatchNorm-backward sums instead of statistics (FastArgs::bx of conv_fast.h): sum(gm * u), sum(gm) into `stats`
-  const void* bx; const float* bsc; const float* bsh; int ldbx;
   long rep_stride;
   int tiles_w, tiles_hw, ntiles, tpw;      // tiles per output row / per image / in total / per workgroup
   unsigned magic_hw, magic_tw;             // div_magic(tiles_hw), div_magic(tiles_w)
@@ -91,7 +89,6 @@ __device__ __forceinline__ band_rsrc_t band_rsrc(const void* base) {
 template <int K, int BN, int VAR, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
   constexpr bool DBG = (VAR & 128) != 0;                  // diagnostic build: honours p.dbg (timing breakdowns, wrong results)
-  constexpr bool BX = (VAR & 8) != 0;                     // BatchNorm-backward sums in the epilogue (BandArgs::bx)
   const int dbg = DBG ? p.dbg : 0;
   using C = BandCfg<K, BN, NW>;
   using T = bf16_t;
@@ -179,20 +176,7 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
     for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
 
   float* const red = reinterpret_cast<float*>(smem + 2 * HB + 2 * WB);
-  if constexpr (BX) { if (tid < 2 * BN) red[tid] = 0.f; }   // LDS accumulators of the two sums (published by the first stage barrier)
   auto flush_stats = [&](int grp) {                        // every wave; ends with the sums of `grp` added to p.stats
-    if constexpr (BX) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                        // every wave's LDS atomics of this group are in
-      if (tid < 2 * BN) {
-        const int which = tid / BN, m = tid - which * BN;
-        const float tot = red[tid];
-        red[tid] = 0.f;                                    // next group's epilogues come after further stage barriers
-        if (m < p.Cout)
-          atomicAdd(p.stats + (long)(blockIdx.x % p.nrep) * p.rep_stride + ((long)grp * 2 + which) * p.stats_ld + m, (double)tot);
-      }
-      return;
-    }
 #pragma unroll
     for (int mi = 0; mi < NT_CO; ++mi) {
 #pragma unroll
@@ -356,26 +340,18 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
         const long pix0 = (long)(coh0 + RPW * wave) * p.Wo + cow0 + (lg & 1) * 16 + l15;   // this lane's pixel of row q = 0 after the swap
         T* const d0 = yb + pix0 * p.ldy + 8 * (lg >> 1);
         const T* const r0 = rb + pix0 * p.ldres + 8 * (lg >> 1);
-        const T* const u0 = BX ? (const T*)p.bx + ((long)cb * p.Ho * p.Wo + pix0) * p.ldbx + 8 * (lg >> 1) : nullptr;
+        // q outside, mi inside: the four 32-byte pieces of a pixel's 128-byte line leave in four CONSECUTIVE store
+        // instructions and merge in L2 (with mi outside, WRITE_SIZE read 1.8x the output: partial lines written back)
 #pragma unroll
-        for (int mi = 0; mi < NT_CO; ++mi) {
-          float t1[8], t2[8], sc8[8], sh8[8];                  // BX: this lane's 8 channels, both rows of the wave
-          if constexpr (BX) {
-            const float* scp = p.bsc + (long)grp * p.Cout + mi * 16 + 8 * (lg >> 1);
-            const float* shp = p.bsh + (long)grp * p.Cout + mi * 16 + 8 * (lg >> 1);
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(scp), a1 = *reinterpret_cast<const f32x4*>(scp + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(shp), b1 = *reinterpret_cast<const f32x4*>(shp + 4);
+        for (int q = 0; q < NT_PIX / 2; ++q) {               // pixel tiles 2q, 2q+1: the two 16-pixel halves of one row
+          T* dst = d0 + (long)q * p.Wo * p.ldy;
+          const T* rsrc = r0 + (long)q * p.Wo * p.ldres;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { sc8[j] = a0[j]; sc8[4 + j] = a1[j]; sh8[j] = b0[j]; sh8[4 + j] = b1[j]; t1[j] = t1[4 + j] = t2[j] = t2[4 + j] = 0.f; }
-          }
-#pragma unroll
-          for (int q = 0; q < NT_PIX / 2; ++q) {             // pixel tiles 2q, 2q+1: the two 16-pixel halves of one row
-            T* dst = d0 + (long)q * p.Wo * p.ldy;
-            const T* rsrc = r0 + (long)q * p.Wo * p.ldres;
+          for (int mi = 0; mi < NT_CO; ++mi) {
             const f32x4 v0 = acc[mi][2 * q], v1 = acc[mi][2 * q + 1];
             const u32x2 o0 = u32x2{pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3])};
             const u32x2 o1 = u32x2{pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3])};
-            if (!BX && p.stats) {
+            if (p.stats) {
               const f32x4 w0 = f32x4{bflo(o0[0]), bfhi(o0[0]), bflo(o0[1]), bfhi(o0[1])};
               const f32x4 w1 = f32x4{bflo(o1[0]), bfhi(o1[0]), bflo(o1[1]), bfhi(o1[1])};
 #pragma unroll
@@ -404,30 +380,9 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
               o = u32x4{e0[0], e1[0], e0[1], e1[1]};
             }
             if (!(dbg & 8)) *reinterpret_cast<u32x4*>(dst + mi * 16) = o;
-            if constexpr (BX) {
-              const u32x4 uu = *reinterpret_cast<const u32x4*>(u0 + (long)q * p.Wo * p.ldbx + mi * 16);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float g0 = bflo(o[e]), g1 = bfhi(o[e]), x0 = bflo(uu[e]), x1 = bfhi(uu[e]);
-                const float m0 = fmaf(x0, sc8[2 * e], sh8[2 * e]) > 0.f ? g0 : 0.f;
-                const float m1 = fmaf(x1, sc8[2 * e + 1], sh8[2 * e + 1]) > 0.f ? g1 : 0.f;
-                t1[2 * e] = fmaf(m0, x0, t1[2 * e]); t2[2 * e] += m0;
-                t1[2 * e + 1] = fmaf(m1, x1, t1[2 * e + 1]); t2[2 * e + 1] += m1;
-              }
-            }
-          }
-          if constexpr (BX) {                                // over the 16 pixels of the DPP row, then one LDS atomic per sum
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float a = row16_sum(t1[j]), c2 = row16_sum(t2[j]);
-              if (l15 == 0) {
-                atomicAdd(&red[mi * 16 + 8 * (lg >> 1) + j], a);
-                atomicAdd(&red[BN + mi * 16 + 8 * (lg >> 1) + j], c2);
-              }
-            }
           }
         }
-        epi_counted = !(dbg & 8) && !p.res && !BX;       // (the addend's / u's loads sit among the stores)
+        epi_counted = !(dbg & 8) && !p.res;              // (the addend's loads sit among the stores)
       } else {
 #pragma unroll
         for (int ni = 0; ni < NT_PIX; ++ni) {
@@ -462,20 +417,7 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = 0.f;
             }
-            if constexpr (BX) {
-              if (valid) {
-                const T* up = (const T*)p.bx + ((long)cb * p.Ho * p.Wo + (long)oh * p.Wo + ow) * p.ldbx;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  if (co + r < p.Cout) {
-                    const float x0 = Elem<T>::ld(up + co + r);
-                    const float gm = fmaf(x0, p.bsc[(long)grp * p.Cout + co + r], p.bsh[(long)grp * p.Cout + co + r]) > 0.f ? v[r] : 0.f;
-                    atomicAdd(&red[co + r], gm * x0);          // ragged tiles only: no need to be clever
-                    atomicAdd(&red[BN + co + r], gm);
-                  }
-                }
-              }
-            } else if (p.stats) {
+            if (p.stats) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) { s1[mi][r] += v[r]; s2[mi][r] = fmaf(v[r], v[r], s2[mi][r]); }
             }
@@ -523,7 +465,6 @@ int launch_band(BandArgs& a, hipStream_t s) {
   // other orders; 4 waves (one per SIMD, 64 x 128 register tiles) measured 265 us — the partner wave's cover is worth more
   // than the quarter of LDS reads saved.  VAR 128: diagnostic build that honours SDHIP_TUNE_BAND_DBG.
   a.dbg &= 0xff;
-  if (a.bx) return a.Mpad > 32 ? launch_band_bn<K, 64, 8 + 5>(a, grid, s) : launch_band_bn<K, 32, 8 + 5>(a, grid, s);
   if (a.Mpad > 32) return a.dbg ? launch_band_bn<K, 64, 128 + 5>(a, grid, s) : launch_band_bn<K, 64, 5>(a, grid, s);
   return launch_band_bn<K, 32, 5>(a, grid, s);
 }

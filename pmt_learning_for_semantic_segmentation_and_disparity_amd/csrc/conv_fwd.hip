@@ -514,8 +514,8 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     if (gemm1x1_ok(g, (in_scale || stats) ? groups : 1)) return launch_gemm_any(g, s);
   }
   // ---- persistent whole-CU kernel (conv_band.h): the full-resolution 5x5 layers, bf16, <= 64 channels either side ----
-  if ((!bx || (stats && Cout % 8 == 0 && ldbx % 8 == 0 && ((uintptr_t)bx & 15) == 0 && !bias && act == 0)) && omul == 1 && dtype == SDHIP_BF16 && kh == 5 && kw == 5 && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
-      (bx || !((accumulate || addend) && stats)) && !(accumulate && addend) && (!addend || (ldadd % 8 == 0 && ((uintptr_t)addend & 15) == 0)) && Cin % 8 == 0 && (Cin <= 32 || Cin == 64) && a.Mpad <= 64 && a.Mpad >= 32 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
+  if (!bx && omul == 1 && dtype == SDHIP_BF16 && kh == 5 && kw == 5 && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
+      !((accumulate || addend) && stats) && !(accumulate && addend) && (!addend || (ldadd % 8 == 0 && ((uintptr_t)addend & 15) == 0)) && Cin % 8 == 0 && (Cin <= 32 || Cin == 64) && a.Mpad <= 64 && a.Mpad >= 32 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
       (long)B * H * W * ldx * 2 < (long)kBandOob && band_ok(sdhip_cdiv(Ho, 16) * sdhip_cdiv(Wo, 32) * B) && !dg.conv_generic && !dg.conv_no_band) {
     BandArgs f;
     f.x = x; f.wp = wpacked; f.y = y; f.bias = bias; f.stats = stats;
@@ -523,7 +523,6 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     f.Cin = Cin; f.ldx = ldx; f.Cout = Cout; f.Mpad = a.Mpad; f.ldy = ldy;
     f.bpg = B / groups; f.act = act; f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride;
     f.res = addend ? addend : (accumulate ? y : nullptr); f.ldres = addend ? ldadd : ldy;
-    f.bx = bx; f.ldbx = ldbx; f.bsc = bsc; f.bsh = bsh;
     return launch_band<5>(f, s);
   }
   if (addend && !bx) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_add: only the persistent 5x5 kernel adds a second tensor in its epilogue (bf16, <= 64 channels, >= 192 tiles of 16x32)");

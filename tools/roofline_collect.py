@@ -40,8 +40,12 @@ busy, _ = avg(m1, DOM, "SQ_VALU_MFMA_BUSY_CYCLES")
 sqbusy, _ = avg(m1, DOM, "SQ_BUSY_CYCLES")
 line = [l for l in open(R + "/stats.log") if l.startswith("{")][-1]
 roof = json.loads(line)["roofline"]
-# FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950 -> x2
-hbm = 2.0 * fetch * 1024 + write * 1024
+# FETCH_SIZE / WRITE_SIZE are reported in KiB.  FETCH_SIZE counts read requests x 64 bytes: a kernel that reads whole 128-byte
+# lines (conv_fast: 128-byte LDS rows) must be doubled (MI355X_MICROARCH.md §HBM); the 64-channel band kernel fetches every
+# pixel as two 64-byte halves in different chunks — 64-byte requests, counted exactly (calibrated against the 32-channel
+# layer and the halo arithmetic: profiles/r02_band_traffic_calibration.txt)
+fetch_scale = 1.0 if DOM == "conv_band_kernel" else 2.0
+hbm = fetch_scale * fetch * 1024 + write * 1024
 dur_cycles = float(conv["AverageNs"]) * 2.4            # 2.4 GHz shader clock
 # SQ_VALU_MFMA_BUSY_CYCLES sums, over the chip's 1024 SIMDs, the cycles a SIMD's matrix pipe was busy
 mfma_frac = busy / (dur_cycles * 1024.0)
@@ -50,7 +54,9 @@ out = {"kernel": conv["Name"][:160], "avg_ns_rocprof": float(conv["AverageNs"]),
        "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write, "launches_fetch": nf, "launches_write": nw,
        "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 2 * 8 * 256 * 512 * 64 * 2 + 64 * 64 * 25 * 2,
        "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": busy, "SQ_BUSY_CYCLES_per_launch": sqbusy, "mfma_busy_frac": round(mfma_frac, 4),
-       "note": "hbm = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes, bench.py --roofline-only; mfma_busy_frac = "
+       "fetch_scale": fetch_scale,
+       "note": "hbm = fetch_scale*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes, bench.py --roofline-only; fetch_scale 1 for the "
+               "64-byte-request pattern of the band kernel (profiles/r02_band_traffic_calibration.txt), 2 for whole-line readers; mfma_busy_frac = "
                "SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles at 2.4 GHz x 1024 SIMDs)"}
 json.dump(out, open("profiles/%s_roofline_traffic.json" % TAG, "w"), indent=1)
 print(json.dumps(out, indent=1))

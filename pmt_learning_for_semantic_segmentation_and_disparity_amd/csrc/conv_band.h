@@ -346,6 +346,7 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
         for (int q = 0; q < NT_PIX / 2; ++q) {               // pixel tiles 2q, 2q+1: the two 16-pixel halves of one row
           T* dst = d0 + (long)q * p.Wo * p.ldy;
           const T* rsrc = r0 + (long)q * p.Wo * p.ldres;
+          u32x4 ov[NT_CO];
 #pragma unroll
           for (int mi = 0; mi < NT_CO; ++mi) {
             const f32x4 v0 = acc[mi][2 * q], v1 = acc[mi][2 * q + 1];
@@ -379,7 +380,11 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
               const u32x2 e1 = __builtin_amdgcn_permlane16_swap(o0[1], o1[1], false, false);
               o = u32x4{e0[0], e1[0], e0[1], e1[1]};
             }
-            if (!(dbg & 8)) *reinterpret_cast<u32x4*>(dst + mi * 16) = o;
+            ov[mi] = o;
+          }
+          if (!(dbg & 8)) {                                  // the line's pieces back to back
+#pragma unroll
+            for (int mi = 0; mi < NT_CO; ++mi) *reinterpret_cast<u32x4*>(dst + mi * 16) = ov[mi];
           }
         }
         epi_counted = !(dbg & 8) && !p.res;              // (the addend's loads sit among the stores)

@@ -284,18 +284,23 @@ __global__ __launch_bounds__(256) void conv_fanout_kernel(const FanArgs p) {
     const int oh = oh0 + r, ow = ow0 + c;
     const bool valid = oh < p.Ho && ow < p.Wo;
     bf16_t* dst = yb + ((long)oh * p.Wo + ow) * p.ldy;
+    f32x4 acc[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-      if (mi * 16 < p.Mpad) {                                      // uniform
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        Mma<bf16_t>::run(acc, af[mi], bfrag);
+      acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (mi * 16 < p.Mpad) Mma<bf16_t>::run(acc[mi], af[mi], bfrag);   // uniform
+    }
+    // the (up to) four 32-byte pieces of a pixel's line in consecutive stores: they merge in L2 (see conv_band.h)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      if (mi * 16 < p.Mpad) {
         const int co = mi * 16 + 4 * lg;
         if (valid && co + 3 < p.Cout) {
-          *reinterpret_cast<u32x2*>(dst + co) = u32x2{pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3])};
+          *reinterpret_cast<u32x2*>(dst + co) = u32x2{pack2bf(acc[mi][0], acc[mi][1]), pack2bf(acc[mi][2], acc[mi][3])};
         } else if (valid) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (co + e < p.Cout) dst[co + e] = f2bf(acc[e]);
+            if (co + e < p.Cout) dst[co + e] = f2bf(acc[mi][e]);
         }
       }
     }

@@ -182,7 +182,7 @@ def test_conv2downup_gradient_slots_match_autograd_adds(cin, cout, k, last, H, W
     (5, 4, 64, 64, 96, 256, 2, False), (5, 4, 64, 64, 100, 250, 2, True), (5, 4, 32, 32, 96, 256, 1, True),
     (3, 4, 64, 64, 48, 64, 2, True), (3, 2, 32, 128, 33, 47, 1, True)])
 def test_data_gradient_with_bn_sums_and_addend(k, B, ci, co, H, W, groups, with_add):
-    """sdhip_conv2d_fwd_bnbwd on the band kernel (5x5) and on the halo-tile kernel (3x3), with and without a second
+    """sdhip_conv2d_fwd_bnbwd on 5x5 and 3x3 shapes (halo-tile kernel with the sums epilogue), with and without a second
     gradient contribution: y = conv (+ addend) equals the separate launches, and the two sums equal sdhip_affine_act_bwd's
     over that y."""
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
@@ -209,6 +209,11 @@ def test_data_gradient_with_bn_sums_and_addend(k, B, ci, co, H, W, groups, with_
     if with_add:
         ref = F.conv2d(x.float().cpu(), w.bfloat16().float().cpu(), None, padding=pad) + a.float().cpu()
         assert (y1.float().cpu() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
+    elif k == 5:
+        # the plain 5x5 launch runs on the persistent kernel, the one with the sums on the halo-tile kernel: same products,
+        # another summation order over (tap, channel half) -> equal up to the bf16 rounding of the stored value
+        d = (y0.float() - y1.float()).abs().max().item()
+        assert d <= 2.0 ** -7 * y0.float().abs().max().item()
     else:
         assert torch.equal(y0, y1)
     both = torch.zeros(2, ops.NREP, groups, co, dtype=torch.float32, device=dev)

@@ -79,12 +79,13 @@ for r in csv.DictReader(open(R + "/step/r_kernel_stats.csv")):
     d = dur[short(r["Name"])]
     d[0] += int(r["Calls"]); d[1] += float(r["TotalDurationNs"])
 with open("profiles/%s_step_counters.csv" % TAG, "w") as f:
-    f.write("kernel,launches (3 eager steps),SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES,hbm_MB (2*FETCH+WRITE),"
-            "hbm_MB_per_launch,avg_us_per_launch (graph run),GB/s,frac_of_8TB/s\n")
-    for k, v in sorted(fam.items(), key=lambda kv: -(2 * kv[1]["fetch"] + kv[1]["write"])):
-        mb = (2 * v["fetch"] + v["write"]) * 1024 / 1e6
+    f.write("kernel,launches (3 eager steps),SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES,hbm_MB (fetch_scale*FETCH+WRITE),"
+            "hbm_MB_per_launch,avg_us_per_launch (graph run),GB/s,frac_of_8TB/s,fetch_scale\n")
+    fs = lambda k: 1.0 if "conv_band_kernel<5, 64" in k else 2.0      # 64-byte read requests: r02_band_traffic_calibration.txt
+    for k, v in sorted(fam.items(), key=lambda kv: -(fs(kv[0]) * kv[1]["fetch"] + kv[1]["write"])):
+        mb = (fs(k) * v["fetch"] + v["write"]) * 1024 / 1e6
         n = max(v["n"], 1)
         us = dur[k][1] / dur[k][0] / 1e3 if dur[k][0] else 0.0
         gbs = (mb / n) / us * 1e3 if us else 0.0
-        f.write('"%s",%d,%.4g,%.4g,%.1f,%.2f,%.1f,%.0f,%.3f\n' % (k, v["n"], v["busy"], v["sq"], mb, mb / n, us, gbs, gbs / 8000.0))
+        f.write('"%s",%d,%.4g,%.4g,%.1f,%.2f,%.1f,%.0f,%.3f,%.0f\n' % (k, v["n"], v["busy"], v["sq"], mb, mb / n, us, gbs, gbs / 8000.0, fs(k)))
 print(open("profiles/%s_step_counters.csv" % TAG).read()[:3000])

@@ -60,13 +60,16 @@ __device__ __forceinline__ u32x4 tr_pair(const unsigned char* lo, const unsigned
 // strided share of the TH x TW pixel tiles and flushes its partial sums once with f32 atomics.
 // Waves: ci_tile = wave % 4 (16 input channels each); the other factor 2 splits the output channels (MB = 64: 32 each)
 // or the taps (MB = 32: even / odd tap slots).
-template <int TH, int TW, int MAXT, int MB, bool DMAX>
+// CIT: input-channel tiles across waves.  4 = a whole 64-channel chunk; 2 = layers with <= 32 input channels (PSMNet's 3-D
+// convolutions, the 32-channel Conv2DownUp blocks): the two tiles that would multiply zero channels are not computed — the
+// freed factor 2 goes to the tap split, so a wave carries half the accumulators, MFMAs and fragment reads per tile.
+template <int TH, int TW, int MAXT, int MB, bool DMAX, int CIT = 4>
 __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   typedef bf16_t T;
   constexpr int V = 8, CK = 64, RB = 128;
   constexpr int NCO = 2;                     // output-channel MFMA tiles per wave
   constexpr int COG = (MB / 16) / NCO;       // output-channel groups across waves: 2 (MB 64) / 1 (MB 32)
-  constexpr int TAPL = 2 / COG;              // waves interleaved over the taps: 1 / 2
+  constexpr int TAPL = (8 / CIT) / COG;      // waves interleaved over the taps: 1 / 2 (CIT 4), 2 / 4 (CIT 2)
   constexpr int MAXTW = (MAXT + TAPL - 1) / TAPL;
   constexpr int NKS = TH * TW / 32;          // MFMA k-steps (32 pixels) per tile
   constexpr int RPR = 64;                    // LDS rows per load round of the 512 lanes
@@ -97,8 +100,8 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   const int t0 = tgi * p.tpb;
   const int nt = qb ? min(qb, p.nq_tot - q * qb) : min(p.tpb, T_ - t0);   // packed: "tap" j is channel chunk q*qb + j
   const int m0 = mb * MB;
-  const int ci_tile = wave & 3;
-  const int rest = wave >> 2;
+  const int ci_tile = wave % CIT;
+  const int rest = wave / CIT;
   const int co_tile0 = (rest % COG) * NCO;
   const int tap_lane = rest / COG;
   const int cin_q = qb ? CK : min(CK, p.Cin - q * CK);   // packed: every flushed chunk writes all 64 columns (pad columns are zeros)
@@ -431,9 +434,9 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   }
 }
 
-template <int TH, int TW, int MAXT, int MB, bool DMAX>
+template <int TH, int TW, int MAXT, int MB, bool DMAX, int CIT = 4>
 int launch_wgf(const WgfArgs& a, hipStream_t s) {
-  auto kern = wgrad_fast_kernel<TH, TW, MAXT, MB, DMAX>;
+  auto kern = wgrad_fast_kernel<TH, TW, MAXT, MB, DMAX, CIT>;
   const int IH = (TH - 1) * a.stride + (a.kh - 1) * a.dil + 1, IW = (TW - 1) * (a.qb ? a.qb : a.stride) + (a.kw - 1) * a.dil + 1;
   const int IWp = (IW + 15) & ~15;
   const int hrounds = (IH * IWp + 63) / 64;
@@ -476,21 +479,25 @@ int launch_wgf(const WgfArgs& a, hipStream_t s) {
 }
 
 // tile choice: wide maps 4x32, else 4x16; 1 = nothing fits (caller falls back to the general kernel)
-template <int MAXT, int MB, bool DMAX>
+template <int MAXT, int MB, bool DMAX, int CIT = 4>
 int launch_wgf_tile(const WgfArgs& a, hipStream_t s) {
   if (a.Wo >= 24) {
-    const int rc = launch_wgf<4, 32, MAXT, MB, DMAX>(a, s);
+    const int rc = launch_wgf<4, 32, MAXT, MB, DMAX, CIT>(a, s);
     if (rc != 1) return rc;
   }
-  return launch_wgf<4, 16, MAXT, MB, DMAX>(a, s);
+  return launch_wgf<4, 16, MAXT, MB, DMAX, CIT>(a, s);
 }
 
 template <bool DMAX>
 int launch_wgf_taps(const WgfArgs& a, int T, hipStream_t s) {
   const bool narrow = a.Cout <= 32;   // 32 output channels per workgroup: the second wave group takes the odd taps instead
   if (T == 1) return narrow ? launch_wgf_tile<1, 32, DMAX>(a, s) : launch_wgf_tile<1, 64, DMAX>(a, s);
-  if (a.tpb <= 9) return narrow ? launch_wgf_tile<9, 32, DMAX>(a, s) : launch_wgf_tile<9, 64, DMAX>(a, s);
-  return launch_wgf_tile<25, 32, DMAX>(a, s);
+  const bool half = a.Cin <= 32 && !sdhip_diag().wgrad_no_half;   // two input-channel tiles instead of four (CIT)
+  if (a.tpb <= 9) {
+    if (half) return narrow ? launch_wgf_tile<9, 32, DMAX, 2>(a, s) : launch_wgf_tile<9, 64, DMAX, 2>(a, s);
+    return narrow ? launch_wgf_tile<9, 32, DMAX>(a, s) : launch_wgf_tile<9, 64, DMAX>(a, s);
+  }
+  return half ? launch_wgf_tile<25, 32, DMAX, 2>(a, s) : launch_wgf_tile<25, 32, DMAX>(a, s);
 }
 
 // chunk-packed 1x1 weight gradient (WgfArgs::qb): 4x16 pixel tiles, up to 4 chunks as taps

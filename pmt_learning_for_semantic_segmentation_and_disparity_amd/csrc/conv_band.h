@@ -18,9 +18,8 @@
 //
 // LDS-DMA bookkeeping (the DMA is inline asm, invisible to the compiler's wait-count pass): the weights of the next
 // stage are issued first after a barrier, the halo rounds of the next chunk after them; `s_waitcnt vmcnt(n)` with
-// n = the halo instructions issued since then waits for exactly the weights.  The epilogue's global stores are drained
-// by the vmcnt(0) that opens the next chunk (loads and stores may retire out of order against each other, so no
-// counted wait ever has a store behind it).
+// n = the halo instructions issued since then waits for exactly the weights; at a tile boundary n = the epilogue's
+// stores (vmcnt retires loads, stores and LDS-DMA together, in issue order).
 #pragma once
 #include <type_traits>
 #include "conv_fast.h"
@@ -54,15 +53,26 @@ struct BandCfg {
   static constexpr int HROWS = IH * IWp;                 // halo rows (64 bytes each) of one chunk
   static constexpr int HR = (HROWS + RPR - 1) / RPR;     // LDS-DMA rounds (NW x 64 lanes x 16 bytes = RPR rows) per halo image
   static constexpr int HB = HROWS * 64;
-  static constexpr int WROWS = K * BN;
+  // A stage = RS kernel rows.  5x5: one row per stage, the weights of the next stage double-buffered.  3x3 (<= 32 input
+  // channels only): the whole kernel is ONE stage per chunk and its 9 taps of weights (<= 37 KB) stay RESIDENT — every
+  // chunk of every tile uses the same ones — so the stage loop issues halo DMA only.
+  static constexpr int RS = K == 3 ? 3 : 1;
+  static constexpr int NSTG = K / RS;                    // stages per chunk
+  static constexpr bool WRES = NSTG == 1;                // weights resident (host: single channel half)
+  static constexpr int TPS = RS * K;                     // taps per stage
+  static constexpr int WROWS = TPS * BN;
   static constexpr int WR = (WROWS + RPR - 1) / RPR;
   static constexpr int WB = WROWS * 64;
-  static constexpr int HPS = (HR + K - 2) / (K - 1);     // halo rounds issued per stage (stages 0 .. K-2 of the previous chunk)
+  static constexpr int NWB = WRES ? 1 : 2;               // weight buffers
+  static constexpr int WRS = WRES ? 0 : WR;              // weight DMA slots per stage
+  // halo rounds of the next chunk issued per stage: spread over stages 0 .. NSTG-2, or all in the only stage
+  static constexpr int HPS = NSTG == 1 ? HR : (HR + NSTG - 2) / (NSTG - 1);
   static constexpr int RED = NW * 2 * BN * 4;            // statistics scratch: [NW waves][2][BN] floats
-  static constexpr int SPT = (WR + HPS + K - 1) / K;     // DMA slots per tap
-  static constexpr size_t LDS = 2 * HB + 2 * WB + RED;
+  static constexpr int SPT = (WRS + HPS + TPS - 1) / TPS;   // DMA slots per tap
+  static constexpr size_t LDS = 2 * HB + NWB * WB + RED;
   static_assert(HROWS % 16 == 0 && WROWS % 16 == 0, "a wave's 16 rows of a DMA round are either all inside or all outside the image");
-  static_assert(HPS * (K - 1) >= HR, "halo rounds must fit the stages of one chunk");
+  static_assert(NSTG == 1 || HPS * (NSTG - 1) >= HR, "halo rounds must fit the stages of one chunk");
+  static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
 // One LDS-DMA instruction through a buffer resource: lane address = base + soff + voff; a lane whose voff is not below
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
     const int tap = row / BN, m = min(row % BN, p.Mpad - 1);
     wv[r] = (tap * p.Mpad + m) * 128 + c_l * 16;
   }
-  const int wrow_bytes = K * p.Mpad * 128;                 // one kernel row of the packed image
+  const int wrow_bytes = C::TPS * p.Mpad * 128;            // one stage (RS kernel rows) of the packed image
   auto w_dma = [&](int r, int j, int h, int wsel) {
     if (r < C::WR && r * RPR + wave * 16 < C::WROWS) band_dma(wv[r], wr, 2 * HB + wsel * WB + r * (RPR * 64) + wave_lds, j * wrow_bytes + h * 64);
   };
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[mi][r] = 0.f; s2[mi][r] = 0.f; }
 
-  float* const red = reinterpret_cast<float*>(smem + 2 * HB + 2 * WB);
+  float* const red = reinterpret_cast<float*>(smem + 2 * HB + C::NWB * WB);
   auto flush_stats = [&](int grp) {                        // every wave; ends with the sums of `grp` added to p.stats
 #pragma unroll
     for (int mi = 0; mi < NT_CO; ++mi) {
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
     }
     const unsigned char* const hb = smem + hsel * HB + wave_row;
 
-    band_static_for<0, K>([&](auto jc) {
+    band_static_for<0, C::NSTG>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       // The weights of this stage (and, entering stage 0, the whole halo image) have landed once at most the operations
       // issued behind them are outstanding: the halo rounds of the previous stage (counted only where every wave issued
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
       if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
 
       const unsigned char* const wl = smem + 2 * HB + wsel * WB + a_base;
-      const unsigned char* const hj = hb + j * (IWp * 64);
+      const unsigned char* const hj = hb + j * C::RS * (IWp * 64);
       u32x4 af[2][NT_CO], bf[2][NT_PIX];
       if constexpr (DBG) if (dbg & 32) {
 #pragma unroll
@@ -254,34 +264,34 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) { if (q < NT_CO) af[i][q] = u32x4{0x3f803f80u, (unsigned)tid, 0x3f803f80u, 0x3f803f80u}; bf[i][q] = u32x4{0x3f803f80u, 0x3f803f80u, (unsigned)lane, 0x3f803f80u}; }
       }
-      auto load = [&](int set, int kw) {
+      auto load = [&](int set, int t) {                     // tap t of the stage: kernel row t / K of it, column t % K
         if (dbg & 32) return;
 #pragma unroll
-        for (int mi = 0; mi < NT_CO; ++mi) af[set][mi] = *reinterpret_cast<const u32x4*>(wl + kw * (BN * 64) + mi * 1024);
+        for (int mi = 0; mi < NT_CO; ++mi) af[set][mi] = *reinterpret_cast<const u32x4*>(wl + t * (BN * 64) + mi * 1024);
 #pragma unroll
         for (int ni = 0; ni < NT_PIX; ++ni)
-          bf[set][ni] = *reinterpret_cast<const u32x4*>(hj + b_k[kw] + ((ni >> 1) * IWp + (ni & 1) * 16) * 64);
+          bf[set][ni] = *reinterpret_cast<const u32x4*>(hj + b_k[t % K] + ((t / K + (ni >> 1)) * IWp + (ni & 1) * 16) * 64);
       };
       // DMA slot s of the stage, issued between the fragment reads of tap s+1 and the MFMAs of tap s: first the weights
       // of the next stage, behind them this stage's share of the next chunk's halo
       auto dma_slot = [&](int sl) {
-        if (sl < C::WR) {
+        if (sl < C::WRS) {
           if (dbg & 2) return;
-          if (j + 1 < K) w_dma(sl, j + 1, ch_half, wsel ^ 1);
+          if (j + 1 < C::NSTG) w_dma(sl, j + 1, ch_half, wsel ^ 1);
           else if (has_next) w_dma(sl, 0, nh, wsel ^ 1);
-        } else if (sl < C::WR + C::HPS) {
+        } else if (sl < C::WRS + C::HPS) {
           if (dbg & 1) return;
-          if (has_next && j < K - 1) halo_dma(j * C::HPS + sl - C::WR, nsoff, hsel ^ 1);
+          if (has_next && (C::NSTG == 1 || j < C::NSTG - 1)) halo_dma(j * C::HPS + sl - C::WRS, nsoff, hsel ^ 1);
         }
       };
       load(0, 0);
 #pragma unroll
-      for (int kw = 0; kw < K; ++kw) {
+      for (int kw = 0; kw < C::TPS; ++kw) {                 // (kw: tap index inside the stage)
         if constexpr ((VAR & 1) != 0) {
 #pragma unroll
           for (int sl = kw * C::SPT; sl < (kw + 1) * C::SPT; ++sl) dma_slot(sl);
         }
-        if (kw + 1 < K) load((kw + 1) & 1, kw + 1);
+        if (kw + 1 < C::TPS) load((kw + 1) & 1, kw + 1);
         if constexpr ((VAR & 1) == 0) {
 #pragma unroll
           for (int sl = kw * C::SPT; sl < (kw + 1) * C::SPT; ++sl) dma_slot(sl);
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
           }
         }
       }
-      wsel ^= 1;
+      if constexpr (!C::WRES) wsel ^= 1;
     });
 
     epi_counted = false;
@@ -470,7 +480,11 @@ int launch_band(BandArgs& a, hipStream_t s) {
   // other orders; 4 waves (one per SIMD, 64 x 128 register tiles) measured 265 us — the partner wave's cover is worth more
   // than the quarter of LDS reads saved.  VAR 128: diagnostic build that honours SDHIP_TUNE_BAND_DBG.
   a.dbg &= 0xff;
-  if (a.Mpad > 32) return a.dbg ? launch_band_bn<K, 64, 128 + 5>(a, grid, s) : launch_band_bn<K, 64, 5>(a, grid, s);
+  if constexpr (K == 5) {
+    if (a.Mpad > 32) return a.dbg ? launch_band_bn<K, 64, 128 + 5>(a, grid, s) : launch_band_bn<K, 64, 5>(a, grid, s);
+  } else {
+    if (a.Mpad > 32) return launch_band_bn<K, 64, 5>(a, grid, s);
+  }
   return launch_band_bn<K, 32, 5>(a, grid, s);
 }
 

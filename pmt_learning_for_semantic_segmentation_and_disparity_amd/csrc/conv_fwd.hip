@@ -513,9 +513,12 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     g.stats_ld = a.stats_ld; g.nrep = a.nrep; g.rep_stride = a.rep_stride;
     if (gemm1x1_ok(g, (in_scale || stats) ? groups : 1)) return launch_gemm_any(g, s);
   }
-  // ---- persistent whole-CU kernel (conv_band.h): the full-resolution 5x5 layers, bf16, <= 64 channels either side ----
-  if (!bx && omul == 1 && dtype == SDHIP_BF16 && kh == 5 && kw == 5 && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
-      !((accumulate || addend) && stats) && !(accumulate && addend) && (!addend || (ldadd % 8 == 0 && ((uintptr_t)addend & 15) == 0)) && Cin % 8 == 0 && (Cin <= 32 || Cin == 64) && a.Mpad <= 64 && a.Mpad >= 32 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
+  // ---- persistent whole-CU kernel (conv_band.h): the full-resolution 5x5 layers (<= 64 channels either side) and the 3x3
+  //      layers with <= 32 input channels (weights resident in LDS), bf16 ----
+  const bool band5 = kh == 5 && kw == 5 && (Cin <= 32 || Cin == 64);
+  const bool band3 = kh == 3 && kw == 3 && Cin <= 32 && !dg.conv_no_band3;
+  if (!bx && omul == 1 && dtype == SDHIP_BF16 && (band5 || band3) && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
+      !((accumulate || addend) && stats) && !(accumulate && addend) && (!addend || (ldadd % 8 == 0 && ((uintptr_t)addend & 15) == 0)) && Cin % 8 == 0 && a.Mpad <= 64 && a.Mpad >= 32 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
       (long)B * H * W * ldx * 2 < (long)kBandOob && band_ok(sdhip_cdiv(Ho, 16) * sdhip_cdiv(Wo, 32) * B) && !dg.conv_generic && !dg.conv_no_band) {
     BandArgs f;
     f.x = x; f.wp = wpacked; f.y = y; f.bias = bias; f.stats = stats;
@@ -523,7 +526,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     f.Cin = Cin; f.ldx = ldx; f.Cout = Cout; f.Mpad = a.Mpad; f.ldy = ldy;
     f.bpg = B / groups; f.act = act; f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride;
     f.res = addend ? addend : (accumulate ? y : nullptr); f.ldres = addend ? ldadd : ldy;
-    return launch_band<5>(f, s);
+    return band5 ? launch_band<5>(f, s) : launch_band<3>(f, s);
   }
   if (addend && !bx) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_add: only the persistent 5x5 kernel adds a second tensor in its epilogue (bf16, <= 64 channels, >= 192 tiles of 16x32)");
   // ---- fast path (conv_fast.h): 16-byte-aligned pixels on both sides, halo-tile mode ----

@@ -35,6 +35,7 @@ static void diag_fill() {
   g_diag.conv_no_thin = env_set("SDHIP_CONV_NO_THIN");
   g_diag.conv_no_gemm = env_set("SDHIP_CONV_NO_GEMM");
   g_diag.conv_no_band = env_set("SDHIP_CONV_NO_BAND");
+  g_diag.conv_no_band3 = env_set("SDHIP_CONV_NO_BAND3");
   g_diag.wgrad_generic = env_set("SDHIP_WGRAD_GENERIC");
   g_diag.wgrad_no_pack = env_set("SDHIP_WGRAD_NO_PACK");
   g_diag.wgrad_force_pack = env_set("SDHIP_WGRAD_FORCE_PACK");

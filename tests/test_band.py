@@ -15,14 +15,20 @@ CASES = [  # name, B, Cin, Cout, H, W, kind, act
     ("c64_32", 2, 64, 32, 128, 400, 'conv', 2),             # two halves, BN = 32, sigmoid epilogue
     ("c64_48", 2, 64, 48, 128, 400, 'conv', 0),             # Cout not a multiple of the block: general store path
     ("d64_64", 2, 64, 64, 112, 448, 'deconv', 0),           # ConvTranspose2dSame: flipped taps, asymmetric crop
+    # 3x3, <= 32 input channels: one stage per chunk, weights resident in LDS
+    ("k3_32_32", 4, 32, 32, 96, 256, 'conv', 1, 3),
+    ("k3_16_64_ragged", 2, 16, 64, 100, 450, 'conv', 0, 3),
+    ("k3_d32_32", 2, 32, 32, 112, 448, 'deconv', 0, 3),
+    ("k3_32_48", 2, 32, 48, 128, 400, 'conv', 2, 3),
 ]
 
 
 def _ref_conv(x, w, b, kind, act):
+    pad = w.shape[-1] // 2
     if kind == 'conv':
-        y = F.conv2d(x, w, b, padding=2)
+        y = F.conv2d(x, w, b, padding=pad)
     else:
-        y = F.conv_transpose2d(x, w, b, padding=2)
+        y = F.conv_transpose2d(x, w, b, padding=pad)
     if act == 1:
         y = torch.relu(y)
     elif act == 2:
@@ -38,10 +44,11 @@ def _rel(a, b):
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_band_conv_matches_f32_reference(case):
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
-    name, B, ci, co, H, W, kind, act = case
+    name, B, ci, co, H, W, kind, act = case[:8]
+    k = case[8] if len(case) > 8 else 5
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10007)
     x = torch.randn(B, ci, H, W, generator=g).bfloat16().float()
-    wshape = (co, ci, 5, 5) if kind == 'conv' else (ci, co, 5, 5)
+    wshape = (co, ci, k, k) if kind == 'conv' else (ci, co, k, k)
     w = (torch.randn(wshape, generator=g) * 0.05).bfloat16().float()
     b = torch.randn(co, generator=g)
     gy = torch.randn(B, co, H, W, generator=g).bfloat16().float()

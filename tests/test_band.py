@@ -230,3 +230,23 @@ def test_data_gradient_with_bn_sums_and_addend(k, B, ci, co, H, W, groups, with_
     ref_s = both.double().sum(1)                  # [2][groups][C]
     got = sums.sum(0).permute(1, 0, 2)
     assert (ref_s - got).abs().max().item() <= 3e-4 * ref_s.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,dil,B,co,H,W", [(5, 1, 2, 64, 100, 450), (1, 1, 4, 64, 33, 47), (3, 2, 2, 32, 40, 70), (5, 1, 2, 24, 16, 32)])
+def test_fanout_conv_one_input_channel(k, dil, B, co, H, W):
+    """conv_fanout_kernel (one input channel -> <= 64 output channels, taps as the MFMA reduction axis; the data gradient of
+    the disparity head and of the attention gates) against an f32 convolution of the same bf16-rounded operands."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    g = torch.Generator().manual_seed(k * 31 + co)
+    x = torch.randn(B, H, W, 1, generator=g).cuda().bfloat16()
+    xp, ldx = ops.alloc_nhwc(B, 1, H, W, torch.bfloat16, "cuda")            # pixel stride padded to 8 elements, as in the step
+    xp.copy_(x.permute(0, 3, 1, 2))
+    w = (torch.randn(co, 1, k, k, generator=g) * 0.2).cuda()
+    wp = ops.packed_weight(w, 'conv', 'fwd', torch.bfloat16)
+    pad = dil * (k - 1) // 2
+    y = ops.empty_nhwc(B, co, H, W, torch.bfloat16, "cuda")
+    ops._conv_launch(xp, ldx, wp, y, co, None, None, None, None, B, H, W, 1, H, W, co, k, k, 1, dil, pad, pad, False, 1, 0, False)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).float().cpu(), w.bfloat16().float().cpu(), None, padding=pad, dilation=dil)
+    assert (y.float().cpu() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-6

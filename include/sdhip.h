@@ -146,11 +146,17 @@ int sdhip_conv2d_fwd_add(const void* x, const void* wpacked, void* y, const void
  * own over y and u.  u: [B][Ho][Wo] pixels of ldu elements, Cout of them used.  addend (optional, as sdhip_conv2d_fwd_add):
  * y = conv + addend, sums taken over that total — the convbn + ReLU layers of Conv2DownUp (models/dsnet_t2.py:80-117), whose
  * output gradient is the next layer's data gradient plus a skip gradient.  bf16, Cout % 4 == 0; consumer:
- * sdhip_bn_bwd_apply_fin_d.  SDHIP_ERR_UNSUPPORTED when the shape has no kernel with this epilogue. */
+ * sdhip_bn_bwd_apply_fin_d.  SDHIP_ERR_UNSUPPORTED when the shape has no kernel with this epilogue.
+ * mode 1 ("apply", addend required and allowed to be y): the launch is the 1x1 data gradient of a DenseNet layer AND the first
+ * phase of norm1's backward over it (models/densenet.py:41-45,75-93: conv1 <- relu1 <- norm1 <- concatenated features):
+ *     y = addend + gm * scale[g][c],  gm = conv(x) where u*scale + shift > 0 else 0
+ * — the masked, scaled gradient accumulated into the slab's gradient — and the two reductions go, as f32, to
+ * ((float*)sums)[which][rep][g][c] (which = 0: sum gm*u, 1: sum gm; [2][sums_nrep][groups][Cout], zeroed by the caller): the
+ * dscale / dshift replicas of sdhip_affine_act_bwd, so its consumers (sdhip_stats_fix_fin, sdhip_bn_finalize_bwd) are unchanged. */
 int sdhip_conv2d_fwd_bnbwd(const void* x, const void* wpacked, void* y, double* sums, int sums_ld, int sums_nrep,
                            const void* u, int ldu, const float* scale, const float* shift, const void* addend, int ldadd,
                            int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,
-                           int kh, int kw, int dil, int pad_t, int pad_l, int groups, int dtype, void* stream);
+                           int kh, int kw, int dil, int pad_t, int pad_l, int groups, int mode, int dtype, void* stream);
 
 /* One sub-pixel phase of nn.ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1) (models_psmnet/stackhourglass.py:25-29;
  * 2-D: D = kd = 1): output voxel 2m + off of an axis receives input m with kernel tap 1 when off = 0, and inputs m, m+1

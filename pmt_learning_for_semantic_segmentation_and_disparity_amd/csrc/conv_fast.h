@@ -40,6 +40,10 @@ struct FastArgs {
   // sum(y), sum(y^2).  nullptr: plain statistics.
   const void* bx; const float* bsc; const float* bsh; int ldbx;
   const void* res; int ldres;   // BX launches only: y = result + res (a second gradient contribution, same geometry as y)
+  // bx_mode 1 ("apply"): y = res + gm * bsc — the whole first phase of sdhip_affine_act_bwd with accumulate: the masked,
+  // scaled gradient is ADDED to res (which may be y itself) and the two sums go, as f32, to ((float*)stats)[which][rep][group][Cout]
+  // (the dscale / dshift replicas that sdhip_affine_act_bwd fills); bx_groups = number of statistics groups
+  int bx_mode, bx_groups;
 };
 
 // source of every padding / dead lane of an LDS-DMA load
@@ -468,6 +472,20 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
           const long pix = (long)oh * p.Wo + ow;
           const u32x2 uu = *reinterpret_cast<const u32x2*>(ub + pix * p.ldbx + co);
           f32x4 v = acc[mi][ni];
+          const float u4[4] = {bflo(uu[0]), bfhi(uu[0]), bflo(uu[1]), bfhi(uu[1])};
+          if (p.bx_mode == 1) {                 // uniform: mask and scale the convolution's value, then add it to res
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(rb + pix * p.ldres + co);
+            const float r4[4] = {bflo(rr[0]), bfhi(rr[0]), bflo(rr[1]), bfhi(rr[1])};
+            float o4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float gm = fmaf(u4[r], sc[r], sh[r]) > 0.f ? v[r] : 0.f;
+              s1[mi][r] = fmaf(gm, u4[r], s1[mi][r]);
+              s2[mi][r] += gm;
+              o4[r] = fmaf(gm, sc[r], r4[r]);
+            }
+            *reinterpret_cast<u32x2*>(yb + pix * p.ldy + co) = u32x2{pack2bf(o4[0], o4[1]), pack2bf(o4[2], o4[3])};
+          } else {
           if (p.res) {                          // uniform
             const u32x2 rr = *reinterpret_cast<const u32x2*>(rb + pix * p.ldres + co);
             v += f32x4{bflo(rr[0]), bfhi(rr[0]), bflo(rr[1]), bfhi(rr[1])};
@@ -475,12 +493,12 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
           const u32x2 o = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
           *reinterpret_cast<u32x2*>(yb + pix * p.ldy + co) = o;
           const float g4[4] = {bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1])};
-          const float u4[4] = {bflo(uu[0]), bfhi(uu[0]), bflo(uu[1]), bfhi(uu[1])};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float gm = fmaf(u4[r], sc[r], sh[r]) > 0.f ? g4[r] : 0.f;
             s1[mi][r] = fmaf(gm, u4[r], s1[mi][r]);
             s2[mi][r] += gm;
+          }
           }
         }
       }
@@ -583,7 +601,11 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
       if (n0 + m < p.Cout) {
         const float tot = red[(0 * 2 + which) * BN + m] + red[(1 * 2 + which) * BN + m] +
                           red[(2 * 2 + which) * BN + m] + red[(3 * 2 + which) * BN + m];
-        atomicAdd(p.stats + (long)((blockIdx.x + blockIdx.z) % p.nrep) * p.rep_stride + ((long)grp * 2 + which) * p.stats_ld + n0 + m, (double)tot);
+        const long rep = (blockIdx.x + blockIdx.z) % p.nrep;
+        if (BX && p.bx_mode == 1)
+          atomicAdd(reinterpret_cast<float*>(p.stats) + (((long)which * p.nrep + rep) * p.bx_groups + grp) * p.Cout + n0 + m, tot);
+        else
+          atomicAdd(p.stats + rep * p.rep_stride + ((long)grp * 2 + which) * p.stats_ld + n0 + m, (double)tot);
       }
     }
   }

@@ -428,7 +428,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
                            int in_relu, int groups, int act, int accumulate,
                            int dtype, void* stream, int omul, int ooz, int ooy, int oox,
                            const void* bx = nullptr, int ldbx = 0, const float* bsc = nullptr, const float* bsh = nullptr,
-                           const void* addend = nullptr, int ldadd = 0) {
+                           const void* addend = nullptr, int ldadd = 0, int bx_mode = 0) {
   SDHIP_CHECK_ARG(x && wpacked && y, "conv2d_fwd: null pointer");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv2d_fwd: unknown dtype %d", dtype);
   SDHIP_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_fwd: empty tensor");
@@ -543,7 +543,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride; f.tail = (Cin % V) != 0;
     f.omul = omul; f.ooz = ooz; f.ooy = ooy; f.oox = oox;
     f.bx = bx; f.ldbx = ldbx; f.bsc = bsc; f.bsh = bsh;
-    f.res = bx ? addend : nullptr; f.ldres = ldadd;
+    f.res = bx ? addend : nullptr; f.ldres = ldadd; f.bx_mode = bx_mode; f.bx_groups = groups;
     f.dma = !in_scale && !f.tail;
     bool fbig = big;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -652,7 +652,8 @@ extern "C" int sdhip_conv2d_fwd_add(const void* x, const void* wpacked, void* y,
 extern "C" int sdhip_conv2d_fwd_bnbwd(const void* x, const void* wpacked, void* y, double* sums, int sums_ld, int sums_nrep,
                                       const void* u, int ldu, const float* scale, const float* shift, const void* addend, int ldadd,
                                       int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,
-                                      int kh, int kw, int dil, int pad_t, int pad_l, int groups, int dtype, void* stream) {
+                                      int kh, int kw, int dil, int pad_t, int pad_l, int groups, int mode, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(mode == 0 || (mode == 1 && addend), "conv2d_fwd_bnbwd: mode 1 (apply) needs the tensor the result is added to");
   SDHIP_CHECK_ARG(dtype == SDHIP_BF16, "conv2d_fwd_bnbwd: bf16 only");
   SDHIP_CHECK_ARG(sums && u && scale && shift && ldu >= Cout && Cout % 4 == 0 && ldu % 4 == 0 && ((uintptr_t)u & 7) == 0 &&
                   ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
@@ -660,7 +661,7 @@ extern "C" int sdhip_conv2d_fwd_bnbwd(const void* x, const void* wpacked, void* 
   SDHIP_CHECK_ARG(!addend || (ldadd >= Cout && ldadd % 4 == 0 && ((uintptr_t)addend & 7) == 0), "conv2d_fwd_bnbwd: addend misaligned");
   return conv2d_fwd_impl(x, wpacked, y, nullptr, nullptr, nullptr, sums, sums_ld, sums_nrep, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy,
                          kh, kw, 1, dil, pad_t, pad_l, 1, 1, 1, 1, 0, 0, groups, 0, 0, dtype, stream, 1, 0, 0, 0, u, ldu, scale, shift,
-                         addend, ldadd);
+                         addend, ldadd, mode);
 }
 
 // One sub-pixel phase of a stride-2 transposed convolution (see include/sdhip.h): a stride-1 correlation whose outputs are

@@ -62,6 +62,9 @@ def _wgrad(x, ldx, dy, lddy, weight, B, H, W, Cin, Cout, k, pad, in_scale, in_sh
     return gw
 
 
+FUSE1_MAX_PIX = 16384     # maps up to this many pixels: norm1's backward rides in the 1x1 data gradient (blocks 3-4 at 256x512)
+
+
 class _DenseBlockFn(torch.autograd.Function):
     """(slab, slab statistics) = dense_block(x0); see the module docstring."""
 
@@ -159,7 +162,7 @@ class _DenseBlockFn(torch.autograd.Function):
                 # ... whose epilogue also takes norm2's two backward reductions (no pass of its own over gp2 and y1)
                 sums2 = ops._zeros((NREP, groups, 2, mid), torch.float64, dev)[0]
                 call("sdhip_conv2d_fwd_bnbwd", ptr(dy2), ptr(wd2), ptr(gp2), ptr(sums2), mid, NREP, ptr(y1), mid,
-                     ptr(sc2), ptr(sh2), None, 0, B, H, W, growth, growth, H, W, mid, mid, 3, 3, 1, 1, 1, groups, dt, st)
+                     ptr(sc2), ptr(sh2), None, 0, B, H, W, growth, growth, H, W, mid, mid, 3, 3, 1, 1, 1, groups, 0, dt, st)
             else:
                 ops._conv_launch(dy2, growth, wd2, gp2, mid, None, None, None, None, B, H, W, growth, H, W, mid, 3, 3, 1, 1, 1, 1,
                                  False, 1, 0, False)
@@ -185,16 +188,30 @@ class _DenseBlockFn(torch.autograd.Function):
                     call("sdhip_stats_fix", ptr(gp2), mid, ptr(y1), mid, ptr(gp2), mid, ptr(dS2), mid, npix, mid, groups, dt, st)
             # (6) conv1 (1x1): data gradient w.r.t. relu(norm1(slab[:Cin])), weight gradient
             wd1 = ops.packed_weight(layer.conv1.weight, 'conv', 'dgrad', dtype)
-            gp1 = ops.empty_nhwc(B, Cin, H, W, dtype, dev)
-            ops._conv_launch(gp2, mid, wd1, gp1, Cin, None, None, None, None, B, H, W, mid, H, W, Cin, 1, 1, 1, 1, 0, 0,
-                             False, 1, 0, False)
-            gw1 = _wgrad(slab, Ct, gp2, mid, layer.conv1.weight, B, H, W, Cin, mid, 1, 0, sc1, sh1, groups, dt)
             # (7) through relu + norm1's affine, accumulated into the slab gradient; (8) norm1's statistics -> dS
+            fused1 = False
             if fuse and li > 0:
                 # reductions now; the per-channel finalize rides on the next layer's stats_fix launch
                 both, pz = ops._zeros((2, NREP, groups, Cin), torch.float32, dev)
-                call("sdhip_affine_act_bwd", ptr(gp1), Cin, ptr(slab), Ct, ptr(g_slab), Ct, ptr(sc1), ptr(sh1), ptr(both[0]), ptr(both[1]),
-                     NREP, npix, Cin, groups, 1, 1, int(pz), dt, st)
+                if dtype == torch.bfloat16 and npix <= FUSE1_MAX_PIX and not _lib_mod.DIAG_NO_BNBWD_EPILOGUE:
+                    # small maps: the 1x1 data gradient itself masks, scales and accumulates into the slab gradient and takes
+                    # the two reductions (mode 1 of sdhip_conv2d_fwd_bnbwd): gp1 is never written, one launch less per layer
+                    rc = _lib_mod._lib.sdhip_conv2d_fwd_bnbwd(ptr(gp2), ptr(wd1), ptr(g_slab), ptr(both), Cin, NREP, ptr(slab), Ct,
+                                                              ptr(sc1), ptr(sh1), ptr(g_slab), Ct, B, H, W, mid, mid, H, W, Cin, Ct,
+                                                              1, 1, 1, 0, 0, groups, 1, dt, st)
+                    if rc == 0:
+                        fused1 = True
+                    elif rc != _lib_mod.ERR_UNSUPPORTED:
+                        raise _lib_mod.SdhipError("sdhip_conv2d_fwd_bnbwd failed (%d): %s" % (rc, _lib_mod._lib.sdhip_last_error().decode()))
+            if not fused1:
+                gp1 = ops.empty_nhwc(B, Cin, H, W, dtype, dev)
+                ops._conv_launch(gp2, mid, wd1, gp1, Cin, None, None, None, None, B, H, W, mid, H, W, Cin, 1, 1, 1, 1, 0, 0,
+                                 False, 1, 0, False)
+            gw1 = _wgrad(slab, Ct, gp2, mid, layer.conv1.weight, B, H, W, Cin, mid, 1, 0, sc1, sh1, groups, dt)
+            if fuse and li > 0:
+                if not fused1:
+                    call("sdhip_affine_act_bwd", ptr(gp1), Cin, ptr(slab), Ct, ptr(g_slab), Ct, ptr(sc1), ptr(sh1), ptr(both[0]), ptr(both[1]),
+                         NREP, npix, Cin, groups, 1, 1, int(pz), dt, st)
                 tg, tb = ops._grad_target(layer.norm1.weight), ops._grad_target(layer.norm1.bias)
                 direct = tg is not None and tb is not None
                 dgam = tg if direct else torch.empty(Cin, dtype=torch.float32, device=dev)

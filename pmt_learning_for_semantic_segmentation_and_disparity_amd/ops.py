@@ -490,7 +490,7 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
             rc = _lib._lib.sdhip_conv2d_fwd_bnbwd(ptr(g), ptr(wd), ptr(gpost), ptr(sums), Cin, NREP, ptr(bn_slot.u), bn_slot.ldu,
                                                   ptr(bn_slot.scale), ptr(bn_slot.shift), ptr(ov), ldo, B, spec.Ho, spec.Wo, Cout, ldg,
                                                   H, W, Cin, ldgp, spec.kh, spec.kw, spec.dil, spec.dil * (spec.kh - 1) - spec.pad_t,
-                                                  spec.dil * (spec.kw - 1) - spec.pad_l, bn_slot.groups, dtype_code(xv), stream_ptr())
+                                                  spec.dil * (spec.kw - 1) - spec.pad_l, bn_slot.groups, 0, dtype_code(xv), stream_ptr())
             if rc == 0:
                 bn_slot.sums, bn_slot.gptr = sums, gpost.data_ptr()
                 fused_bn = True

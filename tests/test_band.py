@@ -211,7 +211,7 @@ def test_data_gradient_with_bn_sums_and_addend(k, B, ci, co, H, W, groups, with_
     y1 = ops.empty_nhwc(B, co, H, W, torch.bfloat16, dev)
     sums = torch.zeros(ops.NREP, groups, 2, co, dtype=torch.float64, device=dev)
     call("sdhip_conv2d_fwd_bnbwd", ptr(x), ptr(wp), ptr(y1), ptr(sums), co, ops.NREP, ptr(u), co, ptr(sc), ptr(sh),
-         ptr(a) if with_add else None, co if with_add else 0, B, H, W, ci, ci, H, W, co, co, k, k, 1, pad, pad, groups, dt, stream_ptr())
+         ptr(a) if with_add else None, co if with_add else 0, B, H, W, ci, ci, H, W, co, co, k, k, 1, pad, pad, groups, 0, dt, stream_ptr())
     torch.cuda.synchronize()
     if with_add:
         ref = F.conv2d(x.float().cpu(), w.bfloat16().float().cpu(), None, padding=pad) + a.float().cpu()

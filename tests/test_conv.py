@@ -277,10 +277,49 @@ def test_hip_dgrad_with_bn_backward_sums(B, H, W, Cin, Cout, groups):
     y1 = ops.empty_nhwc(B, Cout, H, W, torch.bfloat16, dev)
     sums = torch.zeros(ops.NREP, groups, 2, Cout, dtype=torch.float64, device=dev)
     call("sdhip_conv2d_fwd_bnbwd", ptr(x), ptr(wd), ptr(y1), ptr(sums), Cout, ops.NREP, ptr(u), Cout, ptr(sc), ptr(sh), None, 0,
-         B, H, W, Cin, Cin, H, W, Cout, Cout, 3, 3, 1, 1, 1, groups, dt, stream_ptr())
+         B, H, W, Cin, Cin, H, W, Cout, Cout, 3, 3, 1, 1, 1, groups, 0, dt, stream_ptr())
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
     ref = both.double().sum(1)                     # [2][groups][C]
     got = sums.sum(0).permute(1, 0, 2)             # [2][groups][C]
     scale = ref.abs().max().item()
     assert (ref - got).abs().max().item() <= 2e-4 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,K,C,Ct,groups", [(4, 16, 32, 128, 256, 512, 2), (2, 8, 16, 128, 992, 1024, 1), (4, 20, 36, 128, 96, 160, 2)])
+def test_hip_1x1_dgrad_apply_mode(B, H, W, K, C, Ct, groups):
+    """Mode 1 of sdhip_conv2d_fwd_bnbwd (DenseNet: the 1x1 data gradient that also performs the first phase of norm1's
+    backward): slab gradient and reductions equal the two separate launches (conv, then sdhip_affine_act_bwd with
+    accumulate) up to the rounding of the intermediate the fused launch never stores."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd._lib import call, ptr, stream_ptr, dtype_code
+    dev = "cuda"
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, H, W, K, generator=g).to(dev).bfloat16().permute(0, 3, 1, 2)              # gradient of the 1x1 conv's output
+    slab = torch.randn(B, H, W, Ct, generator=g).to(dev).bfloat16().permute(0, 3, 1, 2)          # features (u = first C channels)
+    gs0 = torch.randn(B, H, W, Ct, generator=g).to(dev).bfloat16().permute(0, 3, 1, 2)           # slab gradient so far
+    w = (torch.randn(K, C, 1, 1, generator=g) * 0.1).to(dev)                                      # forward conv C -> K
+    sc = (torch.rand(groups, C, generator=g) + 0.5).to(dev)
+    sh = (torch.randn(groups, C, generator=g) * 0.3).to(dev)
+    wd = ops.packed_weight(w, 'conv', 'dgrad', torch.bfloat16)
+    dt = dtype_code(x)
+    npix = B * H * W
+    # separate launches
+    gp = ops.empty_nhwc(B, C, H, W, torch.bfloat16, dev)
+    ops._conv_launch(x, K, wd, gp, C, None, None, None, None, B, H, W, K, H, W, C, 1, 1, 1, 1, 0, 0, False, 1, 0, False)
+    gs_ref = gs0.clone(memory_format=torch.preserve_format)
+    both0 = torch.zeros(2, ops.NREP, groups, C, dtype=torch.float32, device=dev)
+    call("sdhip_affine_act_bwd", ptr(gp), C, ptr(slab), Ct, ptr(gs_ref), Ct, ptr(sc), ptr(sh), ptr(both0[0]), ptr(both0[1]), ops.NREP,
+         npix, C, groups, 1, 1, 0, dt, stream_ptr())
+    # fused
+    gs = gs0.clone(memory_format=torch.preserve_format)
+    both = torch.zeros(2, ops.NREP, groups, C, dtype=torch.float32, device=dev)
+    call("sdhip_conv2d_fwd_bnbwd", ptr(x), ptr(wd), ptr(gs), ptr(both), C, ops.NREP, ptr(slab), Ct, ptr(sc), ptr(sh), ptr(gs), Ct,
+         B, H, W, K, K, H, W, C, Ct, 1, 1, 1, 0, 0, groups, 1, dt, stream_ptr())
+    torch.cuda.synchronize()
+    a, b = gs.float()[:, :C], gs_ref.float()[:, :C]
+    assert (a - b).abs().max().item() <= 3e-2 * b.abs().max().item()
+    assert torch.equal(gs.float()[:, C:], gs0.float()[:, C:])                 # channels beyond C untouched
+    ra, rb = both.double().sum(1), both0.double().sum(1)
+    assert (ra - rb).abs().max().item() <= 2e-2 * rb.abs().max().item()

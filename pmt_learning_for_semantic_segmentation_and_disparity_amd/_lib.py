@@ -142,6 +142,7 @@ DIAG_NO_FUSED_BN = bool(_diag_switch("SDHIP_DIAG_NO_FUSED_BN"))
 DIAG_NO_SIDE = bool(_diag_switch("SDHIP_DIAG_NO_SIDE"))
 DIAG_NO_GRAD_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_GRAD_SLOTS"))
 DIAG_NO_BN_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_BN_SLOTS"))
+TUNE_FUSE1_MAX_PIX = int(_diag_switch("SDHIP_TUNE_FUSE1_MAX_PIX") or 32768)
 DIAG_NO_BNBWD_EPILOGUE = bool(_diag_switch("SDHIP_DIAG_NO_BNBWD_EPILOGUE"))
 DIAG_STEM_S2D = _diag_switch("SDHIP_STEM_S2D")
 

@@ -62,7 +62,9 @@ def _wgrad(x, ldx, dy, lddy, weight, B, H, W, Cin, Cout, k, pad, in_scale, in_sh
     return gw
 
 
-FUSE1_MAX_PIX = 16384     # maps up to this many pixels: norm1's backward rides in the 1x1 data gradient (blocks 3-4 at 256x512)
+# maps up to this many pixels: norm1's backward rides in the 1x1 data gradient (blocks 2-4 at 256x512; measured 16384 / 32768 /
+# 131072 -> 25.36 / 25.29 / 25.30 ms: on the 64x128 maps of block 1 the streaming GEMM + separate pass is as fast)
+FUSE1_MAX_PIX = _lib_mod.TUNE_FUSE1_MAX_PIX
 
 
 class _DenseBlockFn(torch.autograd.Function):

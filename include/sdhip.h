@@ -127,6 +127,20 @@ int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                      int in_relu, int groups, int act, int accumulate,
                      int dtype, void* stream);
 
+/* y = conv(relu(BatchNorm_train(x)), wpacked) with the BatchNorm finalized INSIDE the launch — the norm2 -> relu2 -> conv2 of a
+ * DenseNet layer (models/densenet.py:41-45,86-93) without a per-channel kernel between conv1's epilogue, which wrote the batch
+ * statistics in_stats (f64 [in_stats_nrep <= 4][groups][2][in_stats_ld]: sum, sum of squares), and this launch, whose input
+ * prologue needs scale = gamma / sqrt(var + eps), shift = beta - mean * scale: every workgroup derives them for its statistics
+ * group (arithmetic of sdhip_bn_finalize), workgroup 0 also writes scale / shift / mean / invstd ([groups][Cin], read by the
+ * backward pass) and updates running_mean / running_var (groups in order, momentum as nn.BatchNorm2d; NULL: not tracked).
+ * out_stats: as `stats` of sdhip_conv2d_fwd.  Stride 1, no dilation, Cin <= 256; f32 and bf16. */
+int sdhip_conv2d_fwd_bnpro(const void* x, const void* wpacked, void* y, double* out_stats, int out_stats_ld, int out_stats_nrep,
+                           const double* in_stats, int in_stats_ld, int in_stats_nrep, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* scale_out, float* shift_out, float* mean_out,
+                           float* invstd_out, double count, float eps, float momentum,
+                           int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,
+                           int kh, int kw, int pad_t, int pad_l, int groups, int dtype, void* stream);
+
 /* y = conv(x, wpacked) + addend: a data gradient that lands on a tensor with a second consumer — x1 / x2 of Conv2DownUp
  * (models/dsnet_t2.py:80-117) feed the next convolution AND a skip add — written as the SUM of both contributions (addend =
  * the skip's gradient, [B][Ho][Wo] pixels of ldadd elements), summed in f32 and rounded once, instead of autograd running an

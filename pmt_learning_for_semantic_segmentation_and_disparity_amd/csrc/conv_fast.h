@@ -44,7 +44,17 @@ struct FastArgs {
   // scaled gradient is ADDED to res (which may be y itself) and the two sums go, as f32, to ((float*)stats)[which][rep][group][Cout]
   // (the dscale / dshift replicas that sdhip_affine_act_bwd fills); bx_groups = number of statistics groups
   int bx_mode, bx_groups;
+  // Consumer-side BatchNorm finalize (sdhip_conv2d_fwd_bnpro; register-staging launches only): the input prologue's
+  // scale / shift are derived HERE from the batch statistics the producing convolution's epilogue wrote — no per-channel
+  // kernel between the two convolutions.  pin_stats: f64 [pin_nrep][groups][2][pin_ld]; workgroup (0,0,0) also writes
+  // scale / shift / mean / invstd ([groups][Cin], for the backward pass) and updates the running statistics.
+  const double* pin_stats; int pin_ld, pin_nrep, pin_groups, pin_off;
+  const float* pin_gamma; const float* pin_beta;
+  float* pin_scale; float* pin_shift; float* pin_mean; float* pin_invstd; float* pin_rmean; float* pin_rvar;
+  float pin_eps, pin_momentum; double pin_count;
 };
+
+constexpr int kPinMaxC = 256;   // input channels the consumer-side finalize table holds
 
 // source of every padding / dead lane of an LDS-DMA load
 __device__ __attribute__((aligned(16))) unsigned int sdhip_zero16[4] = {0u, 0u, 0u, 0u};
@@ -164,6 +174,9 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);   // LDS byte address of this wave's KiB in round 0 of smem
   const unsigned magic_iwp = p.magic_iwp;   // host-computed: a 64-bit division per wave is ~100 instructions of kernel start-up
   constexpr bool dma = DMA;
+  // (scale, shift) table of the consumer-side finalize: 2 x kPinMaxC floats behind the kernel's other dynamic LDS (pin_off)
+  float (*const ptab)[kPinMaxC] = reinterpret_cast<float (*)[kPinMaxC]>(smem + (DMA ? 0 : p.pin_off));
+  const bool has_pro = p.in_scale != nullptr || (!DMA && p.pin_stats != nullptr);
   const int h_rows = IH * IWp;
   const int h_rounds = (h_rows + RPR - 1) / RPR;
   int h_src[HPF];     // small tiles: element offset of the lane's chunk inside one depth slice per round, or -1 (padding)
@@ -202,6 +215,13 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     if (ch0 < p.Cin) {   // Cin % V == 0 whenever a prologue is fused (host: the tail path never carries one)
       const float* sc = p.in_scale + grp * p.Cin + ch0;
       const float* sf = p.in_shift + grp * p.Cin + ch0;
+      if constexpr (!DMA) {
+        if (p.pin_stats) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) { psc[e] = ptab[0][ch0 + e]; psf[e] = ptab[1][ch0 + e]; }
+          return;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < V; e += 4) {
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(sc + e), b4 = *reinterpret_cast<const f32x4*>(sf + e);
@@ -240,14 +260,14 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     const int ch0 = chunk_of(qq) * CKS + c_l * V;
     const int din = slice_of(qq);
     const bool ok = din >= 0 && din < p.D && ch0 < p.Cin;
-    if (p.in_scale) prologue_load(ch0);
+    if (has_pro) prologue_load(ch0);
 #pragma unroll
     for (int j = 0; j < HPF; ++j) {
       if (j < h_rounds) {
         u32x4 raw = rh[j];
         if (ok && h_src[j] >= 0) {
           if (p.tail) raw = mask_tail(raw, ch0);
-          if (p.in_scale) raw = prologue(raw);
+          if (has_pro) raw = prologue(raw);
         }
         *reinterpret_cast<u32x4*>(dst + j * 4096 + tid16) = raw;
       }
@@ -269,7 +289,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     if constexpr (dma) {
       for (int j = 0; j < h_rounds; ++j) glds16(src_of(j), (unsigned)(dst - smem) + j * 4096 + wave_lds);
     } else {
-      if (p.in_scale) prologue_load(ch0);
+      if (has_pro) prologue_load(ch0);
       for (int j0 = 0; j0 < h_rounds; j0 += 4) {
         u32x4 raw[4];
         bool in[4];
@@ -285,7 +305,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
         for (int j = 0; j < 4; ++j) {
           if (j0 + j < h_rounds) {
             if (in[j] && p.tail) raw[j] = mask_tail(raw[j], ch0);
-            if (in[j] && p.in_scale) raw[j] = prologue(raw[j]);
+            if (in[j] && has_pro) raw[j] = prologue(raw[j]);
             *reinterpret_cast<u32x4*>(dst + (j0 + j) * 4096 + tid16) = raw[j];
           }
         }
@@ -372,6 +392,54 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     }
   };
 
+  if constexpr (!DMA) {
+    if (p.pin_stats) {   // uniform: scale / shift of this workgroup's statistics group, arithmetic of bn_finalize_kernel
+      const int G = p.pin_groups;
+      for (int c = tid; c < p.Cin; c += 256) {
+        double a1 = 0., a2 = 0.;
+        for (int r = 0; r < p.pin_nrep; ++r) {
+          const double* Sr = p.pin_stats + (long)r * G * 2 * p.pin_ld;
+          a1 += Sr[((long)grp * 2 + 0) * p.pin_ld + c];
+          a2 += Sr[((long)grp * 2 + 1) * p.pin_ld + c];
+        }
+        const double mu = a1 / p.pin_count;
+        double var = a2 / p.pin_count - mu * mu;
+        if (var < 0.) var = 0.;
+        const float inv = (float)(1.0 / sqrt(var + (double)p.pin_eps));
+        const float scv = (p.pin_gamma ? p.pin_gamma[c] : 1.f) * inv;
+        ptab[0][c] = scv;
+        ptab[1][c] = (float)((double)(p.pin_beta ? p.pin_beta[c] : 0.f) - mu * (double)scv);
+      }
+      if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {   // the one writer: backward-pass vectors, running statistics
+        for (int c = tid; c < p.Cin; c += 256) {
+          const float gm = p.pin_gamma ? p.pin_gamma[c] : 1.f, bt = p.pin_beta ? p.pin_beta[c] : 0.f;
+          float rm = p.pin_rmean ? p.pin_rmean[c] : 0.f, rv = p.pin_rvar ? p.pin_rvar[c] : 0.f;
+          for (int g = 0; g < G; ++g) {
+            double a1 = 0., a2 = 0.;
+            for (int r = 0; r < p.pin_nrep; ++r) {
+              const double* Sr = p.pin_stats + (long)r * G * 2 * p.pin_ld;
+              a1 += Sr[((long)g * 2 + 0) * p.pin_ld + c];
+              a2 += Sr[((long)g * 2 + 1) * p.pin_ld + c];
+            }
+            const double mu = a1 / p.pin_count;
+            double var = a2 / p.pin_count - mu * mu;
+            if (var < 0.) var = 0.;
+            const float inv = (float)(1.0 / sqrt(var + (double)p.pin_eps));
+            const float scv = gm * inv;
+            p.pin_scale[g * p.Cin + c] = scv;
+            p.pin_shift[g * p.Cin + c] = (float)((double)bt - mu * (double)scv);
+            p.pin_mean[g * p.Cin + c] = (float)mu;
+            p.pin_invstd[g * p.Cin + c] = inv;
+            const double unb = p.pin_count > 1. ? var * p.pin_count / (p.pin_count - 1.) : var;
+            rm = (1.f - p.pin_momentum) * rm + p.pin_momentum * (float)mu;
+            rv = (1.f - p.pin_momentum) * rv + p.pin_momentum * (float)unb;
+          }
+          if (p.pin_rmean) { p.pin_rmean[c] = rm; p.pin_rvar[c] = rv; }
+        }
+      }
+      __syncthreads();
+    }
+  }
   // ---- pipeline over stages (depth tap, channel chunk, tap group) ----
   // The loads of stage st+1 (its tap-group weights and, at a chunk boundary of a small tile, its halo tile) are issued
   // right after the barrier of stage st and land (DMA) or wait in registers behind the MFMAs of stage st.

@@ -418,6 +418,14 @@ size_t halo_bytes_of(const ConvGeom& g, int th, int tw, int per_tap) {
 
 }  // namespace
 
+// consumer-side BatchNorm finalize of the input prologue (sdhip_conv2d_fwd_bnpro; FastArgs::pin_*)
+struct ProStats {
+  const double* stats; int ld, nrep;
+  const float* gamma; const float* beta;
+  float* scale; float* shift; float* mean; float* invstd; float* rmean; float* rvar;
+  float eps, momentum; double count;
+};
+
 static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
                            const float* bias, const float* in_scale, const float* in_shift,
                            double* stats, int stats_ld, int stats_nrep,
@@ -428,7 +436,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
                            int in_relu, int groups, int act, int accumulate,
                            int dtype, void* stream, int omul, int ooz, int ooy, int oox,
                            const void* bx = nullptr, int ldbx = 0, const float* bsc = nullptr, const float* bsh = nullptr,
-                           const void* addend = nullptr, int ldadd = 0, int bx_mode = 0) {
+                           const void* addend = nullptr, int ldadd = 0, int bx_mode = 0, const ProStats* ps = nullptr) {
   SDHIP_CHECK_ARG(x && wpacked && y, "conv2d_fwd: null pointer");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv2d_fwd: unknown dtype %d", dtype);
   SDHIP_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_fwd: empty tensor");
@@ -476,7 +484,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
   hipStream_t s = (hipStream_t)stream;
   const int per_tap_any = (kh > 1 || kw > 1) && dil >= 4 && kd == 1;
   // ---- thin path (conv_thin.h): <= 8 input channels -> 1 output channel on the vector ALUs ----
-  if (!bx && !addend && omul == 1 && Cout == 1 && Cin <= V && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale &&
+  if (!ps && !bx && !addend && omul == 1 && Cout == 1 && Cin <= V && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && stride == 1 && kd == 1 && D == 1 && Do == 1 && !in_scale &&
       !accumulate && kh * kw <= kThinMaxT && Ho == H + 2 * pad_t - dil * (kh - 1) && Wo == W + 2 * pad_l - dil * (kw - 1) &&
       pad_t >= 0 && pad_l >= 0 && !dg.conv_no_thin) {
     ThinArgs t;
@@ -491,7 +499,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     return SDHIP_OK;
   }
   // ---- one input channel fanned out to <= 64 output channels (conv_thin.h): taps as the MFMA reduction axis ----
-  if (!bx && !addend && omul == 1 && dtype == SDHIP_BF16 && fanout_ok(Cin, Cout, kh * kw, stride, kd, ldy, y) && D == 1 && Do == 1 && !in_scale &&
+  if (!ps && !bx && !addend && omul == 1 && dtype == SDHIP_BF16 && fanout_ok(Cin, Cout, kh * kw, stride, kd, ldy, y) && D == 1 && Do == 1 && !in_scale &&
       !accumulate && !stats && !bias && act == 0 && (kh - 1) * dil <= 31 && (kw - 1) * dil <= 31 && (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) < (1L << 31) &&
       B <= 65535 && !dg.conv_no_thin) {
     FanArgs t;
@@ -501,7 +509,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     return launch_fanout(t, s);
   }
   // ---- 1x1 as a streaming GEMM (conv_gemm.h): bf16, plain stride-1 1x1 over whole images ----
-  if (!bx && !addend && omul == 1 && dtype == SDHIP_BF16 && kh == 1 && kw == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && D == 1 && Do == 1 &&
+  if (!ps && !bx && !addend && omul == 1 && dtype == SDHIP_BF16 && kh == 1 && kw == 1 && kd == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && D == 1 && Do == 1 &&
       Ho == H && Wo == W && !accumulate && !dg.conv_generic && !dg.conv_no_gemm) {
     GemmArgs g;
     g.seg[0] = GemmSeg{x, ldx, Cin, 0};
@@ -517,7 +525,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
   //      layers with <= 32 input channels (weights resident in LDS), bf16 ----
   const bool band5 = kh == 5 && kw == 5 && (Cin <= 32 || Cin == 64);
   const bool band3 = kh == 3 && kw == 3 && Cin <= 32 && !dg.conv_no_band3;
-  if (!bx && omul == 1 && dtype == SDHIP_BF16 && (band5 || band3) && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
+  if (!ps && !bx && omul == 1 && dtype == SDHIP_BF16 && (band5 || band3) && kd == 1 && stride == 1 && dil == 1 && D == 1 && Do == 1 && !in_scale &&
       !((accumulate || addend) && stats) && !(accumulate && addend) && (!addend || (ldadd % 8 == 0 && ((uintptr_t)addend & 15) == 0)) && Cin % 8 == 0 && a.Mpad <= 64 && a.Mpad >= 32 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
       (long)B * H * W * ldx * 2 < (long)kBandOob && band_ok(sdhip_cdiv(Ho, 16) * sdhip_cdiv(Wo, 32) * B) && !dg.conv_generic && !dg.conv_no_band) {
     BandArgs f;
@@ -544,7 +552,13 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     f.omul = omul; f.ooz = ooz; f.ooy = ooy; f.oox = oox;
     f.bx = bx; f.ldbx = ldbx; f.bsc = bsc; f.bsh = bsh;
     f.res = bx ? addend : nullptr; f.ldres = ldadd; f.bx_mode = bx_mode; f.bx_groups = groups;
-    f.dma = !in_scale && !f.tail;
+    f.dma = !in_scale && !f.tail && !ps;
+    f.pin_stats = nullptr;
+    if (ps) {
+      f.pin_stats = ps->stats; f.pin_ld = ps->ld; f.pin_nrep = ps->nrep; f.pin_groups = groups; f.pin_gamma = ps->gamma; f.pin_beta = ps->beta;
+      f.pin_scale = ps->scale; f.pin_shift = ps->shift; f.pin_mean = ps->mean; f.pin_invstd = ps->invstd; f.pin_rmean = ps->rmean; f.pin_rvar = ps->rvar;
+      f.pin_eps = ps->eps; f.pin_momentum = ps->momentum; f.pin_count = ps->count;
+    }
     bool fbig = big;
     for (int attempt = 0; attempt < 2; ++attempt) {
       const int th = fbig ? 8 : 4, tw = fbig ? 32 : 16;
@@ -565,6 +579,8 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
         lds = hb + 2 * wbuf(tg);
       }
       if (lds < 4096) lds = 4096;
+      f.pin_off = 0;
+      if (ps) { f.pin_off = (int)lds; lds += 2 * kPinMaxC * sizeof(float); }   // the finalize table sits behind everything else
       if (lds > kMax) { if (!fbig) break; fbig = false; continue; }
       f.tg = tg;
       f.magic_iwp = IWp > 1 ? (unsigned)(0x100000000ULL / (unsigned)IWp) + 1u : 0u;
@@ -576,6 +592,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     }
   }
   if (omul != 1) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_phase: interleaved output needs the aligned fast path (ldx %% 8, ldy %% 4)");
+  if (ps) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_bnpro: needs the aligned fast path (ldx %% 8, ldy %% 4, halo tile within LDS)");
   if (bx) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_bnbwd: needs the aligned fast path (ldx %% 8, ldy %% 4, halo tile within LDS)");
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int th = big ? 8 : 4, tw = big ? 32 : 16;
@@ -636,6 +653,25 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
                                 int dtype, void* stream) {
   return conv2d_fwd_impl(x, wpacked, y, bias, in_scale, in_shift, stats, stats_ld, stats_nrep, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy,
                          kh, kw, stride, dil, pad_t, pad_l, D, Do, kd, sd, pad_d, in_relu, groups, act, accumulate, dtype, stream, 1, 0, 0, 0);
+}
+
+// y = conv(relu(BatchNorm_train(x))) with the BatchNorm finalized inside the launch (see include/sdhip.h).
+extern "C" int sdhip_conv2d_fwd_bnpro(const void* x, const void* wpacked, void* y, double* out_stats, int out_stats_ld, int out_stats_nrep,
+                                      const double* in_stats, int in_stats_ld, int in_stats_nrep, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float* scale_out, float* shift_out, float* mean_out,
+                                      float* invstd_out, double count, float eps, float momentum,
+                                      int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,
+                                      int kh, int kw, int pad_t, int pad_l, int groups, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(in_stats && scale_out && shift_out && mean_out && invstd_out && count >= 1. && in_stats_nrep >= 1 && in_stats_ld >= Cin,
+                  "conv2d_fwd_bnpro: statistics / output vectors missing");
+  SDHIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "conv2d_fwd_bnpro: running_mean / running_var come together");
+  if (Cin > kPinMaxC || in_stats_nrep > 4)
+    SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_bnpro: at most %d input channels and 4 statistics replicas", kPinMaxC);
+  ProStats ps{in_stats, in_stats_ld, in_stats_nrep, gamma, beta, scale_out, shift_out, mean_out, invstd_out, running_mean, running_var,
+              eps, momentum, count};
+  return conv2d_fwd_impl(x, wpacked, y, nullptr, nullptr, nullptr, out_stats, out_stats_ld, out_stats_nrep, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy,
+                         kh, kw, 1, 1, pad_t, pad_l, 1, 1, 1, 1, 0, 1, groups, 0, 0, dtype, stream, 1, 0, 0, 0, nullptr, 0, nullptr, nullptr,
+                         nullptr, 0, 0, &ps);
 }
 
 // y = conv(x) + addend (see include/sdhip.h).

@@ -67,6 +67,9 @@ def _wgrad(x, ldx, dy, lddy, weight, B, H, W, Cin, Cout, k, pad, in_scale, in_sh
 FUSE1_MAX_PIX = _lib_mod.TUNE_FUSE1_MAX_PIX
 
 
+PRO_MAX_PIX = _lib_mod.TUNE_PRO_MAX_PIX    # maps up to this many pixels: norm2 is finalized inside conv2's launch
+
+
 class _DenseBlockFn(torch.autograd.Function):
     """(slab, slab statistics) = dense_block(x0); see the module docstring."""
 
@@ -104,14 +107,34 @@ class _DenseBlockFn(torch.autograd.Function):
                 sc1, sh1, mu1, iv1 = _finalize(S[:, :, :Cin], 1, layer.norm1, count, groups, training, synced=True)
             w1 = ops.packed_weight(layer.conv1.weight, 'conv', 'fwd', dtype)
             y1 = ops.empty_nhwc(B, mid, H, W, dtype, dev)
-            S2 = ops._zeros((NREP, groups, 2, mid), torch.float64, dev)[0] if training else None
+            # norm2's finalize inside conv2's launch (sdhip_conv2d_fwd_bnpro): one dependent node less per layer on the maps
+            # where the tower is a latency chain; its table is built from <= 4 statistics replicas, so conv1 spreads its
+            # epilogue atomics over fewer of them there (few workgroups: little contention)
+            pro2 = fuse and npix <= PRO_MAX_PIX and mid <= 256 and not _lib_mod.DIAG_NO_BNPRO
+            nrep2 = 2 if pro2 else NREP
+            S2 = ops._zeros((nrep2, groups, 2, mid), torch.float64, dev)[0] if training else None
             ops._conv_launch(slab, Ct, w1, y1, mid, None, sc1, sh1, S2, B, H, W, Cin, H, W, mid, 1, 1, 1, 1, 0, 0,
-                             True, groups, 0, False, NREP)
-            sc2, sh2, mu2, iv2 = _finalize(S2, NREP, layer.norm2, count, groups, training)
+                             True, groups, 0, False, nrep2)
             w2 = ops.packed_weight(layer.conv2.weight, 'conv', 'fwd', dtype)
             S3 = ops._zeros((NREP, groups, 2, growth), torch.float64, dev)[0] if training else None
-            ops._conv_launch(y1, mid, w2, slab[:, Cin:Cin + growth], Ct, None, sc2, sh2, S3, B, H, W, mid, H, W, growth,
-                             3, 3, 1, 1, 1, 1, True, groups, 0, False, NREP)
+            done2 = False
+            if pro2:
+                bn2 = layer.norm2
+                sc2, sh2, mu2, iv2 = [torch.empty((groups, mid), dtype=torch.float32, device=dev) for _ in range(4)]
+                rc = _lib_mod._lib.sdhip_conv2d_fwd_bnpro(
+                    ptr(y1), ptr(w2), ptr(slab[:, Cin:Cin + growth]), ptr(S3), S3.stride(-2), NREP, ptr(S2), S2.stride(-2), nrep2,
+                    ptr(bn2.weight), ptr(bn2.bias), ptr(bn2.running_mean), ptr(bn2.running_var), ptr(sc2), ptr(sh2), ptr(mu2), ptr(iv2),
+                    float(count), float(bn2.eps), float(0.1 if bn2.momentum is None else bn2.momentum),
+                    B, H, W, mid, mid, H, W, growth, Ct, 3, 3, 1, 1, groups, dt, stream_ptr())
+                if rc == 0:
+                    ops._bn_track(bn2, groups)
+                    done2 = True
+                elif rc != _lib_mod.ERR_UNSUPPORTED:
+                    raise _lib_mod.SdhipError("sdhip_conv2d_fwd_bnpro failed (%d): %s" % (rc, _lib_mod._lib.sdhip_last_error().decode()))
+            if not done2:
+                sc2, sh2, mu2, iv2 = _finalize(S2, nrep2, layer.norm2, count, groups, training)
+                ops._conv_launch(y1, mid, w2, slab[:, Cin:Cin + growth], Ct, None, sc2, sh2, S3, B, H, W, mid, H, W, growth,
+                                 3, 3, 1, 1, 1, 1, True, groups, 0, False, NREP)
             if training:   # fold the replicas into this layer's slice of the slab statistics
                 if fuse and li + 1 < L:
                     pending = (S3, Cin)          # ... together with the next layer's norm1 finalize

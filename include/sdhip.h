@@ -133,9 +133,15 @@ int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
  * prologue needs scale = gamma / sqrt(var + eps), shift = beta - mean * scale: every workgroup derives them for its statistics
  * group (arithmetic of sdhip_bn_finalize), workgroup 0 also writes scale / shift / mean / invstd ([groups][Cin], read by the
  * backward pass) and updates running_mean / running_var (groups in order, momentum as nn.BatchNorm2d; NULL: not tracked).
- * out_stats: as `stats` of sdhip_conv2d_fwd.  Stride 1, no dilation, Cin <= 256; f32 and bf16. */
+ * out_stats: as `stats` of sdhip_conv2d_fwd.  Stride 1, no dilation, Cin <= 1024; f32 and bf16.
+ * pend_stats (optional): the norm1 -> relu1 -> conv1 of a dense layer (models/densenet.py:41-45,75-85) reads the slab statistics
+ * in_stats (one replica) of which the channels [pend_c0, pend_c0 + pend_n) — the previous layer's output — are still spread over
+ * the replicas pend_stats (f64 [pend_nrep <= 4][groups][2][pend_ld], channel c - pend_c0): they are taken from there and
+ * workgroup 0 folds them into in_stats on the way (what sdhip_bn_fold_finalize does in a launch of its own). */
 int sdhip_conv2d_fwd_bnpro(const void* x, const void* wpacked, void* y, double* out_stats, int out_stats_ld, int out_stats_nrep,
-                           const double* in_stats, int in_stats_ld, int in_stats_nrep, const float* gamma, const float* beta,
+                           double* in_stats, int in_stats_ld, int in_stats_nrep,
+                           const double* pend_stats, int pend_ld, int pend_nrep, int pend_c0, int pend_n,
+                           const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float* scale_out, float* shift_out, float* mean_out,
                            float* invstd_out, double count, float eps, float momentum,
                            int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,

@@ -88,7 +88,7 @@ SIGNATURES = {
     "sdhip_flip_sample": [_p, _p, _i, _p, _i, _i, _p, _i, _i, _p, _l, _i, _p],
     "sdhip_bn_bwd_apply_fin": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _d, _i, _i, _p],
     "sdhip_bn_bwd_apply_fin_d": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _d, _i, _i, _p],
-    "sdhip_conv2d_fwd_bnpro": [_p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _d, _f, _f] + [_i] * 15 + [_p],
+    "sdhip_conv2d_fwd_bnpro": [_p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _d, _f, _f] + [_i] * 15 + [_p],
     "sdhip_conv2d_fwd_add": [_p, _p, _p, _p, _i] + [_i] * 14 + [_p],
     "sdhip_conv2d_fwd_bnbwd": [_p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _i] + [_i] * 17 + [_p],
 }

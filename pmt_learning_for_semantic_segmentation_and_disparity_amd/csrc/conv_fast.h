@@ -48,13 +48,17 @@ struct FastArgs {
   // scale / shift are derived HERE from the batch statistics the producing convolution's epilogue wrote — no per-channel
   // kernel between the two convolutions.  pin_stats: f64 [pin_nrep][groups][2][pin_ld]; workgroup (0,0,0) also writes
   // scale / shift / mean / invstd ([groups][Cin], for the backward pass) and updates the running statistics.
-  const double* pin_stats; int pin_ld, pin_nrep, pin_groups, pin_off;
+  const double* pin_stats; int pin_ld, pin_nrep, pin_groups, pin_off, pin_cs;
   const float* pin_gamma; const float* pin_beta;
   float* pin_scale; float* pin_shift; float* pin_mean; float* pin_invstd; float* pin_rmean; float* pin_rvar;
   float pin_eps, pin_momentum; double pin_count;
+  // ... of a DenseNet slab: channels [pend_c0, pend_c0 + pend_n) are the previous layer's output, whose statistics still sit in
+  // the replicas pend_stats (f64 [pend_nrep][groups][2][pend_ld], channel index c - pend_c0); the writer workgroup folds them
+  // into the slab statistics pin_fold (= pin_stats, writable) on the way.  pend_n = 0: none.
+  const double* pend_stats; double* pin_fold; int pend_ld, pend_nrep, pend_c0, pend_n;
 };
 
-constexpr int kPinMaxC = 256;   // input channels the consumer-side finalize table holds
+constexpr int kPinMaxC = 1024;   // input channels the consumer-side finalize table holds
 
 // source of every padding / dead lane of an LDS-DMA load
 __device__ __attribute__((aligned(16))) unsigned int sdhip_zero16[4] = {0u, 0u, 0u, 0u};
@@ -174,8 +178,9 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);   // LDS byte address of this wave's KiB in round 0 of smem
   const unsigned magic_iwp = p.magic_iwp;   // host-computed: a 64-bit division per wave is ~100 instructions of kernel start-up
   constexpr bool dma = DMA;
-  // (scale, shift) table of the consumer-side finalize: 2 x kPinMaxC floats behind the kernel's other dynamic LDS (pin_off)
-  float (*const ptab)[kPinMaxC] = reinterpret_cast<float (*)[kPinMaxC]>(smem + (DMA ? 0 : p.pin_off));
+  // (scale, shift) table of the consumer-side finalize: 2 x pin_cs floats behind the kernel's other dynamic LDS (pin_off)
+  float* const ptab_sc = reinterpret_cast<float*>(smem + (DMA ? 0 : p.pin_off));
+  float* const ptab_sh = ptab_sc + (DMA ? 0 : p.pin_cs);
   const bool has_pro = p.in_scale != nullptr || (!DMA && p.pin_stats != nullptr);
   const int h_rows = IH * IWp;
   const int h_rounds = (h_rows + RPR - 1) / RPR;
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
       if constexpr (!DMA) {
         if (p.pin_stats) {
 #pragma unroll
-          for (int e = 0; e < V; ++e) { psc[e] = ptab[0][ch0 + e]; psf[e] = ptab[1][ch0 + e]; }
+          for (int e = 0; e < V; ++e) { psc[e] = ptab_sc[ch0 + e]; psf[e] = ptab_sh[ch0 + e]; }
           return;
         }
       }
@@ -395,31 +400,45 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   if constexpr (!DMA) {
     if (p.pin_stats) {   // uniform: scale / shift of this workgroup's statistics group, arithmetic of bn_finalize_kernel
       const int G = p.pin_groups;
-      for (int c = tid; c < p.Cin; c += 256) {
-        double a1 = 0., a2 = 0.;
-        for (int r = 0; r < p.pin_nrep; ++r) {
-          const double* Sr = p.pin_stats + (long)r * G * 2 * p.pin_ld;
-          a1 += Sr[((long)grp * 2 + 0) * p.pin_ld + c];
-          a2 += Sr[((long)grp * 2 + 1) * p.pin_ld + c];
+      auto sums_of = [&](int g, int c, double& a1, double& a2) {   // sum and sum of squares of channel c in group g
+        a1 = 0.; a2 = 0.;
+        const int cp = c - p.pend_c0;
+        if (cp >= 0 && cp < p.pend_n) {
+          for (int r = 0; r < p.pend_nrep; ++r) {
+            const double* Sr = p.pend_stats + (long)r * G * 2 * p.pend_ld;
+            a1 += Sr[((long)g * 2 + 0) * p.pend_ld + cp];
+            a2 += Sr[((long)g * 2 + 1) * p.pend_ld + cp];
+          }
+        } else {
+          for (int r = 0; r < p.pin_nrep; ++r) {
+            const double* Sr = p.pin_stats + (long)r * G * 2 * p.pin_ld;
+            a1 += Sr[((long)g * 2 + 0) * p.pin_ld + c];
+            a2 += Sr[((long)g * 2 + 1) * p.pin_ld + c];
+          }
         }
+      };
+      for (int c = tid; c < p.Cin; c += 256) {
+        double a1, a2;
+        sums_of(grp, c, a1, a2);
         const double mu = a1 / p.pin_count;
         double var = a2 / p.pin_count - mu * mu;
         if (var < 0.) var = 0.;
         const float inv = (float)(1.0 / sqrt(var + (double)p.pin_eps));
         const float scv = (p.pin_gamma ? p.pin_gamma[c] : 1.f) * inv;
-        ptab[0][c] = scv;
-        ptab[1][c] = (float)((double)(p.pin_beta ? p.pin_beta[c] : 0.f) - mu * (double)scv);
+        ptab_sc[c] = scv;
+        ptab_sh[c] = (float)((double)(p.pin_beta ? p.pin_beta[c] : 0.f) - mu * (double)scv);
       }
-      if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {   // the one writer: backward-pass vectors, running statistics
+      if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {   // the one writer: backward-pass vectors, running statistics, fold
         for (int c = tid; c < p.Cin; c += 256) {
           const float gm = p.pin_gamma ? p.pin_gamma[c] : 1.f, bt = p.pin_beta ? p.pin_beta[c] : 0.f;
           float rm = p.pin_rmean ? p.pin_rmean[c] : 0.f, rv = p.pin_rvar ? p.pin_rvar[c] : 0.f;
+          const bool pend = c >= p.pend_c0 && c < p.pend_c0 + p.pend_n;
           for (int g = 0; g < G; ++g) {
-            double a1 = 0., a2 = 0.;
-            for (int r = 0; r < p.pin_nrep; ++r) {
-              const double* Sr = p.pin_stats + (long)r * G * 2 * p.pin_ld;
-              a1 += Sr[((long)g * 2 + 0) * p.pin_ld + c];
-              a2 += Sr[((long)g * 2 + 1) * p.pin_ld + c];
+            double a1, a2;
+            sums_of(g, c, a1, a2);
+            if (pend) {   // nobody reads these slab entries during this launch (every workgroup takes them from the replicas)
+              p.pin_fold[((long)g * 2 + 0) * p.pin_ld + c] = a1;
+              p.pin_fold[((long)g * 2 + 1) * p.pin_ld + c] = a2;
             }
             const double mu = a1 / p.pin_count;
             double var = a2 / p.pin_count - mu * mu;

@@ -424,6 +424,7 @@ struct ProStats {
   const float* gamma; const float* beta;
   float* scale; float* shift; float* mean; float* invstd; float* rmean; float* rvar;
   float eps, momentum; double count;
+  const double* pend; double* fold; int pend_ld, pend_nrep, pend_c0, pend_n;
 };
 
 static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
@@ -558,6 +559,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
       f.pin_stats = ps->stats; f.pin_ld = ps->ld; f.pin_nrep = ps->nrep; f.pin_groups = groups; f.pin_gamma = ps->gamma; f.pin_beta = ps->beta;
       f.pin_scale = ps->scale; f.pin_shift = ps->shift; f.pin_mean = ps->mean; f.pin_invstd = ps->invstd; f.pin_rmean = ps->rmean; f.pin_rvar = ps->rvar;
       f.pin_eps = ps->eps; f.pin_momentum = ps->momentum; f.pin_count = ps->count;
+      f.pend_stats = ps->pend; f.pin_fold = ps->fold; f.pend_ld = ps->pend_ld; f.pend_nrep = ps->pend_nrep; f.pend_c0 = ps->pend_c0; f.pend_n = ps->pend ? ps->pend_n : 0;
     }
     bool fbig = big;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -579,8 +581,8 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
         lds = hb + 2 * wbuf(tg);
       }
       if (lds < 4096) lds = 4096;
-      f.pin_off = 0;
-      if (ps) { f.pin_off = (int)lds; lds += 2 * kPinMaxC * sizeof(float); }   // the finalize table sits behind everything else
+      f.pin_off = 0; f.pin_cs = 0;
+      if (ps) { f.pin_off = (int)lds; f.pin_cs = (Cin + 63) & ~63; lds += 2 * (size_t)f.pin_cs * sizeof(float); }   // the finalize table sits behind everything else
       if (lds > kMax) { if (!fbig) break; fbig = false; continue; }
       f.tg = tg;
       f.magic_iwp = IWp > 1 ? (unsigned)(0x100000000ULL / (unsigned)IWp) + 1u : 0u;
@@ -657,7 +659,9 @@ extern "C" int sdhip_conv2d_fwd(const void* x, const void* wpacked, void* y,
 
 // y = conv(relu(BatchNorm_train(x))) with the BatchNorm finalized inside the launch (see include/sdhip.h).
 extern "C" int sdhip_conv2d_fwd_bnpro(const void* x, const void* wpacked, void* y, double* out_stats, int out_stats_ld, int out_stats_nrep,
-                                      const double* in_stats, int in_stats_ld, int in_stats_nrep, const float* gamma, const float* beta,
+                                      double* in_stats, int in_stats_ld, int in_stats_nrep,
+                                      const double* pend_stats, int pend_ld, int pend_nrep, int pend_c0, int pend_n,
+                                      const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, float* scale_out, float* shift_out, float* mean_out,
                                       float* invstd_out, double count, float eps, float momentum,
                                       int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int ldy,
@@ -665,10 +669,12 @@ extern "C" int sdhip_conv2d_fwd_bnpro(const void* x, const void* wpacked, void* 
   SDHIP_CHECK_ARG(in_stats && scale_out && shift_out && mean_out && invstd_out && count >= 1. && in_stats_nrep >= 1 && in_stats_ld >= Cin,
                   "conv2d_fwd_bnpro: statistics / output vectors missing");
   SDHIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "conv2d_fwd_bnpro: running_mean / running_var come together");
-  if (Cin > kPinMaxC || in_stats_nrep > 4)
+  if (Cin > kPinMaxC || in_stats_nrep > 4 || (pend_stats && pend_nrep > 4))
     SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_bnpro: at most %d input channels and 4 statistics replicas", kPinMaxC);
+  SDHIP_CHECK_ARG(!pend_stats || (pend_n > 0 && pend_c0 >= 0 && pend_c0 + pend_n <= Cin && pend_ld >= pend_n && pend_nrep >= 1 && in_stats_nrep == 1),
+                  "conv2d_fwd_bnpro: bad pending-statistics slice (folding needs single-replica slab statistics)");
   ProStats ps{in_stats, in_stats_ld, in_stats_nrep, gamma, beta, scale_out, shift_out, mean_out, invstd_out, running_mean, running_var,
-              eps, momentum, count};
+              eps, momentum, count, pend_stats, in_stats, pend_ld, pend_nrep, pend_c0, pend_n};
   return conv2d_fwd_impl(x, wpacked, y, nullptr, nullptr, nullptr, out_stats, out_stats_ld, out_stats_nrep, B, H, W, Cin, ldx, Ho, Wo, Cout, ldy,
                          kh, kw, 1, 1, pad_t, pad_l, 1, 1, 1, 1, 0, 1, groups, 0, 0, dtype, stream, 1, 0, 0, 0, nullptr, 0, nullptr, nullptr,
                          nullptr, 0, 0, &ps);

@@ -38,7 +38,7 @@ def _finalize(stats, nrep, bn, count, groups, training, synced=False):
 
 def _fold(ws, S_slice, groups, C, Ct):
     """Fold conv-epilogue replicas (summed over ranks when data parallel) into a channel slice of the slab statistics."""
-    ws, nrep = ops._sync_stats(ws, NREP)
+    ws, nrep = ops._sync_stats(ws, ws.shape[0])
     call("sdhip_stats_replica_sum", ptr(ws), ptr(S_slice), nrep, groups, C, C, Ct, stream_ptr())
 
 
@@ -49,7 +49,7 @@ def _fold_finalize(ws, c_new0, Cn, S, Ct, bn, C, count, groups):
     out = [torch.empty((groups, C), dtype=torch.float32, device=dev) for _ in range(4)]
     ops._bn_track(bn, groups)
     mom = 0.1 if bn.momentum is None else bn.momentum
-    call("sdhip_bn_fold_finalize", ptr(ws), NREP, ws.stride(-2), c_new0, Cn, ptr(S), Ct, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+    call("sdhip_bn_fold_finalize", ptr(ws), ws.shape[0], ws.stride(-2), c_new0, Cn, ptr(S), Ct, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
          ptr(bn.running_var), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, groups, float((count)), float(bn.eps), float(mom),
          stream_ptr())
     return out
@@ -97,33 +97,53 @@ class _DenseBlockFn(torch.autograd.Function):
         saved = []
         pending = None      # (replicas of the previous layer's new channels, their channel offset): folded by the next finalize
         fuse = training and ops.parallel.world_size() == 1
+        small = fuse and npix <= PRO_MAX_PIX and not _lib_mod.DIAG_NO_BNPRO   # finalize kernels folded into the convolutions
+        nrep3 = 2 if small else NREP                      # replicas of a layer's output statistics (read back by <= 4 at a time)
         for li, layer in enumerate(layers):
             Cin = C0 + li * growth
-            if pending is not None:
-                # ONE launch: fold the previous layer's statistics into the slab AND finalize this layer's norm1
-                sc1, sh1, mu1, iv1 = _fold_finalize(pending[0], pending[1], growth, S, Ct, layer.norm1, Cin, count, groups)
-                pending = None
-            else:
-                sc1, sh1, mu1, iv1 = _finalize(S[:, :, :Cin], 1, layer.norm1, count, groups, training, synced=True)
             w1 = ops.packed_weight(layer.conv1.weight, 'conv', 'fwd', dtype)
             y1 = ops.empty_nhwc(B, mid, H, W, dtype, dev)
             # norm2's finalize inside conv2's launch (sdhip_conv2d_fwd_bnpro): one dependent node less per layer on the maps
             # where the tower is a latency chain; its table is built from <= 4 statistics replicas, so conv1 spreads its
             # epilogue atomics over fewer of them there (few workgroups: little contention)
-            pro2 = fuse and npix <= PRO_MAX_PIX and mid <= 256 and not _lib_mod.DIAG_NO_BNPRO
+            pro2 = small and mid <= 1024
             nrep2 = 2 if pro2 else NREP
             S2 = ops._zeros((nrep2, groups, 2, mid), torch.float64, dev)[0] if training else None
-            ops._conv_launch(slab, Ct, w1, y1, mid, None, sc1, sh1, S2, B, H, W, Cin, H, W, mid, 1, 1, 1, 1, 0, 0,
-                             True, groups, 0, False, nrep2)
+            done1 = False
+            if small and Cin <= 1024:
+                # ... and norm1's finalize (with the fold of the previous layer's statistics into the slab's) inside conv1's
+                bn1 = layer.norm1
+                sc1, sh1, mu1, iv1 = [torch.empty((groups, Cin), dtype=torch.float32, device=dev) for _ in range(4)]
+                pw, pc0 = (pending if pending is not None else (None, 0))
+                rc = _lib_mod._lib.sdhip_conv2d_fwd_bnpro(
+                    ptr(slab), ptr(w1), ptr(y1), ptr(S2), S2.stride(-2), nrep2, ptr(S), Ct, 1,
+                    ptr(pw), pw.stride(-2) if pw is not None else 0, pw.shape[0] if pw is not None else 0, pc0, growth if pw is not None else 0,
+                    ptr(bn1.weight), ptr(bn1.bias), ptr(bn1.running_mean), ptr(bn1.running_var), ptr(sc1), ptr(sh1), ptr(mu1), ptr(iv1),
+                    float(count), float(bn1.eps), float(0.1 if bn1.momentum is None else bn1.momentum),
+                    B, H, W, Cin, Ct, H, W, mid, mid, 1, 1, 0, 0, groups, dt, stream_ptr())
+                if rc == 0:
+                    ops._bn_track(bn1, groups)
+                    done1, pending = True, None
+                elif rc != _lib_mod.ERR_UNSUPPORTED:
+                    raise _lib_mod.SdhipError("sdhip_conv2d_fwd_bnpro failed (%d): %s" % (rc, _lib_mod._lib.sdhip_last_error().decode()))
+            if not done1:
+                if pending is not None:
+                    # ONE launch: fold the previous layer's statistics into the slab AND finalize this layer's norm1
+                    sc1, sh1, mu1, iv1 = _fold_finalize(pending[0], pending[1], growth, S, Ct, layer.norm1, Cin, count, groups)
+                    pending = None
+                else:
+                    sc1, sh1, mu1, iv1 = _finalize(S[:, :, :Cin], 1, layer.norm1, count, groups, training, synced=True)
+                ops._conv_launch(slab, Ct, w1, y1, mid, None, sc1, sh1, S2, B, H, W, Cin, H, W, mid, 1, 1, 1, 1, 0, 0,
+                                 True, groups, 0, False, nrep2)
             w2 = ops.packed_weight(layer.conv2.weight, 'conv', 'fwd', dtype)
-            S3 = ops._zeros((NREP, groups, 2, growth), torch.float64, dev)[0] if training else None
+            S3 = ops._zeros((nrep3, groups, 2, growth), torch.float64, dev)[0] if training else None
             done2 = False
             if pro2:
                 bn2 = layer.norm2
                 sc2, sh2, mu2, iv2 = [torch.empty((groups, mid), dtype=torch.float32, device=dev) for _ in range(4)]
                 rc = _lib_mod._lib.sdhip_conv2d_fwd_bnpro(
-                    ptr(y1), ptr(w2), ptr(slab[:, Cin:Cin + growth]), ptr(S3), S3.stride(-2), NREP, ptr(S2), S2.stride(-2), nrep2,
-                    ptr(bn2.weight), ptr(bn2.bias), ptr(bn2.running_mean), ptr(bn2.running_var), ptr(sc2), ptr(sh2), ptr(mu2), ptr(iv2),
+                    ptr(y1), ptr(w2), ptr(slab[:, Cin:Cin + growth]), ptr(S3), S3.stride(-2), nrep3, ptr(S2), S2.stride(-2), nrep2,
+                    None, 0, 0, 0, 0, ptr(bn2.weight), ptr(bn2.bias), ptr(bn2.running_mean), ptr(bn2.running_var), ptr(sc2), ptr(sh2), ptr(mu2), ptr(iv2),
                     float(count), float(bn2.eps), float(0.1 if bn2.momentum is None else bn2.momentum),
                     B, H, W, mid, mid, H, W, growth, Ct, 3, 3, 1, 1, groups, dt, stream_ptr())
                 if rc == 0:
@@ -134,7 +154,7 @@ class _DenseBlockFn(torch.autograd.Function):
             if not done2:
                 sc2, sh2, mu2, iv2 = _finalize(S2, nrep2, layer.norm2, count, groups, training)
                 ops._conv_launch(y1, mid, w2, slab[:, Cin:Cin + growth], Ct, None, sc2, sh2, S3, B, H, W, mid, H, W, growth,
-                                 3, 3, 1, 1, 1, 1, True, groups, 0, False, NREP)
+                                 3, 3, 1, 1, 1, 1, True, groups, 0, False, nrep3)
             if training:   # fold the replicas into this layer's slice of the slab statistics
                 if fuse and li + 1 < L:
                     pending = (S3, Cin)          # ... together with the next layer's norm1 finalize

@@ -397,6 +397,10 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
     }
   };
 
+  // the first weights (LDS-DMA) and, for small tiles, the raw halo loads go out BEFORE the consumer-side finalize below: they
+  // do not depend on it and cover its round trips to the statistics
+  w_issue(0, 0, wl0);
+  if constexpr (PF) halo_issue(0, halo0);
   if constexpr (!DMA) {
     if (p.pin_stats) {   // uniform: scale / shift of this workgroup's statistics group, arithmetic of bn_finalize_kernel
       const int G = p.pin_groups;
@@ -462,8 +466,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   // ---- pipeline over stages (depth tap, channel chunk, tap group) ----
   // The loads of stage st+1 (its tap-group weights and, at a chunk boundary of a small tile, its halo tile) are issued
   // right after the barrier of stage st and land (DMA) or wait in registers behind the MFMAs of stage st.
-  if constexpr (PF) halo_issue(0, halo0); else halo_sync_stage(0, halo0);
-  w_issue(0, 0, wl0);
+  if constexpr (!PF) halo_sync_stage(0, halo0);
   int q = 0, tgi = 0;
   const int S = nqq * ntg;
   for (int st = 0; st < S; ++st) {

@@ -273,11 +273,13 @@ def _pack_rows(w, kind, mode, dt):
 def pack_descriptors(dtype):
     """int64 [n][8] descriptor table {src, dst, M, K, T, stride_m, stride_k, flip} of every cached pack of `dtype`."""
     rows = []
-    for ref, ent in _pack_cache.values():
+    # (a snapshot: the weak-reference callbacks of parameters that die meanwhile — a discarded model being collected — pop
+    #  their entries, which must not happen under a live dictionary iterator)
+    for ref, ent in list(_pack_cache.values()):
         w = ref()
         if w is None:
             continue
-        for (kind, mode, dt), (_, buf) in ent.items():
+        for (kind, mode, dt), (_, buf) in list(ent.items()):
             if dt != dtype:
                 continue
             dtc = _lib.BF16 if dt == torch.bfloat16 else _lib.F32

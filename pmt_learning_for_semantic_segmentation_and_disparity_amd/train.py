@@ -141,6 +141,12 @@ class TrainStep:
                 self._eager(*self.static)
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
+        # No device memory may be released while the stream records (what `torch.cuda.graph` guards against the same way):
+        # collect the garbage of whatever ran before NOW, and keep the cyclic collector off until the capture has ended —
+        # a discarded model collected in the middle of the recording pass frees tensors, fires the weight-cache callbacks
+        # and, after an injected failure, took the process down (tests/test_train.py in the middle of the full suite).
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
         graph = torch.cuda.CUDAGraph()
         # data parallel: the RCCL watchdog thread polls events while we capture; thread-local capture errors keep its
@@ -150,16 +156,22 @@ class TrainStep:
         # __exit__ when the capture was invalidated and then neither restores the current stream nor ends the capture,
         # which leaves the whole process unable to launch (observed on ROCm 7.2: every later call fails with
         # hipErrorStreamCaptureInvalidated).  Here a failure ends the capture explicitly (sdhip_abort_capture).
-        with torch.cuda.stream(cap):
-            graph.capture_begin(capture_error_mode=mode)
-            try:
-                self.loss = self._eager(*self.static)
-                if self._capture_fault is not None:
-                    self._capture_fault()
-                graph.capture_end()
-            except BaseException:
-                self._close_broken_capture(graph, cap)
-                raise
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.stream(cap):
+                graph.capture_begin(capture_error_mode=mode)
+                try:
+                    self.loss = self._eager(*self.static)
+                    if self._capture_fault is not None:
+                        self._capture_fault()
+                    graph.capture_end()
+                except BaseException:
+                    self._close_broken_capture(graph, cap)
+                    raise
+        finally:
+            if gc_was_on:
+                gc.enable()
         torch.cuda.current_stream().wait_stream(cap)
         self.graph = graph
         return self

@@ -270,14 +270,20 @@ def _pack_rows(w, kind, mode, dt):
     return rows
 
 
-def pack_descriptors(dtype):
-    """int64 [n][8] descriptor table {src, dst, M, K, T, stride_m, stride_k, flip} of every cached pack of `dtype`."""
+def pack_descriptors(dtype, owners=None):
+    """int64 [n][8] descriptor table {src, dst, M, K, T, stride_m, stride_k, flip} of the cached packs of `dtype` that belong
+    to the parameters in `owners` (an iterable of tensors; None: every cached pack).  A training step must pass ITS model's
+    parameters: the table is replayed step after step (inside a hipGraph), so a row of another model's weight — or of a
+    per-step temporary such as the space-to-depth stem weight — would keep reading and writing that tensor's memory after
+    it has been freed (a GPU memory fault once the allocator has returned the block: found by the full test suite, where
+    several models are alive at once)."""
+    own = None if owners is None else {id(t) for t in owners}
     rows = []
     # (a snapshot: the weak-reference callbacks of parameters that die meanwhile — a discarded model being collected — pop
     #  their entries, which must not happen under a live dictionary iterator)
     for ref, ent in list(_pack_cache.values()):
         w = ref()
-        if w is None:
+        if w is None or (own is not None and id(w) not in own):
             continue
         for (kind, mode, dt), (_, buf) in list(ent.items()):
             if dt != dtype:

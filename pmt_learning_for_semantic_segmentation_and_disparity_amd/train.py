@@ -75,7 +75,7 @@ class TrainStep:
         """After the first (measuring) step: allocate the zero arena, freeze the weight packs into one batched
         launch, switch parameter gradients to direct accumulation into the flat buffer."""
         self.ctx.allocate_arena()
-        rows = ops.pack_descriptors(self.dtype)
+        rows = ops.pack_descriptors(self.dtype, owners=self.model.parameters())   # this model's weights only
         self.pack_desc = torch.tensor(rows, dtype=torch.int64, device=self.flat_p.device) if rows else None
         self.ctx.frozen_pack = self.pack_desc is not None
         self.ctx.direct_grads = True

@@ -236,3 +236,29 @@ def test_graph_with_side_stream_matches_eager():
     assert ts.use_graph and ts.graph is not None and ts.ctx.side is not None
     assert abs(got[0] - want[2]) <= 2e-3 * max(1.0, abs(want[2])), (got, want)
     assert abs(got[1] - want[3]) <= 2e-2 * max(1.0, abs(want[3])), (got, want)
+
+
+@pytest.mark.gpu
+def test_pack_table_holds_only_the_steps_own_weights():
+    """The batched weight-pack table a TrainStep replays every step (inside its hipGraph) must reference ONLY its own model's
+    parameters: with a second model alive (its packs cached too) and a per-step temporary weight in the cache, every source
+    address of the table lies inside the step's flat parameter buffer."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    batch = synthetic_batch(2, 256, 256)
+    other = _model()                                     # another live model whose weights get packed and cached
+    ops.set_step_context(None)
+    with torch.no_grad():
+        other(batch[0], batch[1])
+    ts = TrainStep(_model(), dtype=torch.float32, use_graph=False, lr=1e-4)
+    for _ in range(2):
+        ts(*batch)                                       # measuring step + the step that arms the services
+    assert ts.pack_desc is not None and ts.pack_desc.shape[0] > 100
+    lo = ts.flat_p.data_ptr()
+    hi = lo + ts.flat_p.numel() * ts.flat_p.element_size()
+    src = ts.pack_desc[:, 0].cpu()
+    assert bool(((src >= lo) & (src < hi)).all())
+    foreign = {p.data_ptr() for p in other.parameters()}
+    assert not (set(src.tolist()) & foreign)
+    del other
+    ops.set_step_context(None)

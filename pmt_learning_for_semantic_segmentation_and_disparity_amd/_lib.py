@@ -145,6 +145,7 @@ DIAG_NO_GRAD_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_GRAD_SLOTS"))
 DIAG_NO_BN_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_BN_SLOTS"))
 TUNE_FUSE1_MAX_PIX = int(_diag_switch("SDHIP_TUNE_FUSE1_MAX_PIX") or 32768)
 TUNE_PRO_MAX_PIX = int(_diag_switch("SDHIP_TUNE_PRO_MAX_PIX") or 32768)
+TUNE_BN_SLOT_MAX_MB = int(_diag_switch("SDHIP_TUNE_BN_SLOT_MAX_MB") or 40)
 DIAG_NO_BNPRO = bool(_diag_switch("SDHIP_DIAG_NO_BNPRO"))
 DIAG_NO_BNBWD_EPILOGUE = bool(_diag_switch("SDHIP_DIAG_NO_BNBWD_EPILOGUE"))
 DIAG_STEM_S2D = _diag_switch("SDHIP_STEM_S2D")

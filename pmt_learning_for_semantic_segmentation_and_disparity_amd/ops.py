@@ -451,7 +451,7 @@ class GradSlot:
         self.exclusive = exclusive
 
 
-BN_SLOT_MAX_BYTES = 40 << 20
+BN_SLOT_MAX_BYTES = _lib.TUNE_BN_SLOT_MAX_MB << 20
 
 
 class BNSlot:

@@ -103,10 +103,15 @@ def kernel_roofline(dtype, B, H, W):
                 break
             except Exception:
                 pass
+    cyc = None
+    try:   # matrix-pipe busy share of the GPU CYCLES of the launch (GRBM_GUI_ACTIVE based; tools/pmc_conv5.sh), committed with the profiles
+        cyc = json.load(open(os.path.join(ROOT, "profiles", "r02_band_counters.json")))["_derived"]["mfma_busy_share_of_gpu_cycles"]
+    except Exception:
+        pass
     return {"bound": "mfma", "kernel": "conv_band_kernel<5x5, 64 out-ch> (persistent, 16x32 tiles, halo prefetched by LDS-DMA) 64->64 @%dx%dx%d" % (B, H, W),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
             "traffic_source": (src + " (PMC passes of `bench.py --roofline-only`, tools/roofline_profile.sh; not measured in this run)") if src else None,
-            "mfma_busy_frac": busy, "algorithmic_bytes": 2 * B * H * W * C * (2 if dtype == torch.bfloat16 else 4) + C * C * 25 * 2,
+            "mfma_busy_frac": busy, "mfma_busy_cycle_frac": cyc, "algorithmic_bytes": 2 * B * H * W * C * (2 if dtype == torch.bfloat16 else 4) + C * C * 25 * 2,
             "ms_per_launch": round(ms, 4)}
 
 

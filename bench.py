@@ -104,8 +104,9 @@ def kernel_roofline(dtype, B, H, W):
             except Exception:
                 pass
     cyc = None
-    try:   # matrix-pipe busy share of the GPU CYCLES of the launch (GRBM_GUI_ACTIVE based; tools/pmc_conv5.sh), committed with the profiles
-        cyc = json.load(open(os.path.join(ROOT, "profiles", "r02_band_counters.json")))["_derived"]["mfma_busy_share_of_gpu_cycles"]
+    try:   # (bench shape only) matrix-pipe busy share of the GPU CYCLES of the launch (GRBM_GUI_ACTIVE based; tools/pmc_conv5.sh), committed with the profiles
+        if dtype == torch.bfloat16 and (B, H, W) == (8, 256, 512):
+            cyc = json.load(open(os.path.join(ROOT, "profiles", "r02_band_counters.json")))["_derived"]["mfma_busy_share_of_gpu_cycles"]
     except Exception:
         pass
     return {"bound": "mfma", "kernel": "conv_band_kernel<5x5, 64 out-ch> (persistent, 16x32 tiles, halo prefetched by LDS-DMA) 64->64 @%dx%dx%d" % (B, H, W),

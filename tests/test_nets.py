@@ -250,3 +250,49 @@ def test_hip_stem_space_to_depth_equals_7x7(dtype, tol, monkeypatch):
     for a, b, name in zip(res["0"], res["1"], ("tap0", "tap1", "conv0.weight.grad", "norm0.weight.grad", "norm0.bias.grad")):
         err = float((a - b).norm() / b.norm().clamp_min(1e-12))
         assert err < tol * (20 if "grad" in name else 1), (name, err)
+
+
+@pytest.mark.gpu
+def test_hip_densenet_bf16_fused_chain_matches_unfused():
+    """bf16 DenseNet towers (B = 8, two statistics groups, 128 x 256) with every in-kernel fusion of the dense-layer chain
+    (consumer-side finalize in conv1 / conv2, norm2's reductions in the 3x3 data gradient, norm1's first phase in the 1x1
+    data gradient) against the same network with those launches kept separate: taps, running statistics and parameter
+    gradients agree to bf16 working precision."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import _lib as L
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.densenet import densenet121
+    x = rand_input(31, "img", (8, 3, 128, 256)).cuda().bfloat16()
+    wts = [0.7, 1.1, 0.9, 1.3, 0.8]
+
+    def run(fused):
+        old = (L.DIAG_NO_BNPRO, L.DIAG_NO_BNBWD_EPILOGUE)
+        L.DIAG_NO_BNPRO = L.DIAG_NO_BNBWD_EPILOGUE = not fused
+        try:
+            m = fill_state_dict(densenet121(), 21).cuda().train()
+            taps = m(x, groups=2)
+            sum(w * (t.float() * t.float()).mean() for w, t in zip(wts, taps)).backward()
+            torch.cuda.synchronize()
+            return ([t.detach().float() for t in taps], {k: p.grad.float().clone() for k, p in m.named_parameters() if p.grad is not None},
+                    {k: v.float().clone() for k, v in m.state_dict().items() if k.endswith("running_var") or k.endswith("running_mean")})
+        finally:
+            L.DIAG_NO_BNPRO, L.DIAG_NO_BNBWD_EPILOGUE = old
+
+    t1, g1, s1 = run(True)
+    t0, g0, s0 = run(False)
+    for a, b in zip(t1, t0):
+        assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b)) < 2e-2
+    for k in s0:
+        assert torch.allclose(s1[k], s0[k], rtol=2e-2, atol=2e-3), k
+    # measured (tests/diag/gpu_densenet_fused_diag.py): median 1.3 %, 90th percentile 2 % between the two chains, while either
+    # is ~57 % (median) away from the f32 gradients of this random-weight tower — the fusions move nothing beyond bf16 noise.
+    # The only large relative difference is norm0.weight, whose gradient (3e-4) is a cancellation residue in both.
+    nmax = max(float(torch.linalg.norm(v)) for v in g0.values())
+    errs, worst = [], 0.0
+    for k in g0:
+        n0 = float(torch.linalg.norm(g0[k]))
+        err = float(torch.linalg.norm(g1[k] - g0[k])) / max(n0, 1e-12)
+        errs.append(err)
+        if n0 >= 1e-2 * nmax:
+            worst = max(worst, err)
+    errs.sort()
+    assert errs[len(errs) // 2] < 0.03 and errs[int(len(errs) * 0.9)] < 0.06, (errs[len(errs) // 2], errs[int(len(errs) * 0.9)])
+    assert worst < 0.15, worst

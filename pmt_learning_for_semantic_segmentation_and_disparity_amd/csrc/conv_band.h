@@ -1,5 +1,6 @@
-// Persistent K x K convolution for the full-resolution 5x5 layers (Conv2DownUp, models/blocks.py of the reference; the
-// ten launches that lead the training step's profile): bf16, stride 1, no dilation, <= 64 input and output channels.
+// Persistent K x K convolution for the full-resolution 5x5 layers (Conv2DownUp, models/dsnet_t2.py:80-117 of the reference;
+// the ten launches that lead the training step's profile) and the 3x3 layers with <= 32 input channels: bf16, stride 1, no
+// dilation, <= 64 input and output channels.
 //
 // What the tap-group pipeline of conv_fast.h cannot do inside its 80 KiB (two workgroups per CU): keep more than one tap
 // of 64x64 weights per stage next to a 64-channel halo tile — 25 stages of 32 MFMAs per wave, a barrier and a DMA drain
@@ -10,7 +11,8 @@
 //   chunk   (tile, 32-channel half of the input): its halo image, (16+K-1) x 40 rows of 64 bytes, is 50 KiB, so TWO fit:
 //           the halo of chunk c+1 streams in by LDS-DMA, a couple of rounds per stage, while chunk c is computed
 //   stage   one kernel ROW of a chunk: K taps x BN rows of 64 bytes of weights (20 KiB), double-buffered; K * 4 * BN/16
-//           MFMAs per wave between two barriers (80 for 5x5 / 64 channels, against 32)
+//           MFMAs per wave between two barriers (80 for 5x5 / 64 channels, against 32).  3x3: the whole kernel is one stage and
+//           its nine taps of weights stay resident (BandCfg::WRES), so the stage loop issues halo DMA only
 //
 // Every fragment address is  buffer + wave row + compile-time constant + one of K per-lane registers:  with the halo
 // row pitch (40) and the 16-pixel column step multiples of 8 rows, the swizzle key of a pixel depends on

@@ -218,15 +218,15 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   float psc[V], psf[V];
   auto prologue_load = [&](int ch0) {
     if (ch0 < p.Cin) {   // Cin % V == 0 whenever a prologue is fused (host: the tail path never carries one)
-      const float* sc = p.in_scale + grp * p.Cin + ch0;
-      const float* sf = p.in_shift + grp * p.Cin + ch0;
       if constexpr (!DMA) {
-        if (p.pin_stats) {
+        if (p.pin_stats) {   // consumer-side finalize: the table built at kernel start
 #pragma unroll
           for (int e = 0; e < V; ++e) { psc[e] = ptab_sc[ch0 + e]; psf[e] = ptab_sh[ch0 + e]; }
           return;
         }
       }
+      const float* sc = p.in_scale + grp * p.Cin + ch0;
+      const float* sf = p.in_shift + grp * p.Cin + ch0;
 #pragma unroll
       for (int e = 0; e < V; e += 4) {
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(sc + e), b4 = *reinterpret_cast<const f32x4*>(sf + e);

@@ -20,6 +20,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+class _LazyTorch:
+    """torch on first use: the parent of a multi-rank launch must stay free of torch / HIP (spawn_ranks), while the helper
+    functions below (and the tools that import this module for them) see an ordinary module."""
+
+    def __getattr__(self, name):
+        import torch as t
+        globals()["torch"] = t
+        return getattr(t, name)
+
+
+torch = _LazyTorch()
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -277,8 +289,6 @@ def main():
         print(json.dumps({"rank": rank, "local_rank": local, "world": world, "master": "%s:%s" % (
             os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")), "pid": os.getpid(), "ppid": os.getppid()}), flush=True)
         return
-    global torch
-    import torch
     ndev = torch.cuda.device_count()
     if a.backend == "nccl" and local >= ndev:
         raise SystemExit("bench.py: rank %d needs GPU %d but this node shows %d (RCCL wants one GPU per rank)" % (rank, local, ndev))
@@ -339,6 +349,12 @@ def main():
                           "world_size": (torch.distributed.get_world_size() if world > 1 else 1),
                           "backend": ("rccl" if a.backend == "nccl" else "gloo (rehearsal, not a result)") if world > 1 else None},
                "loss": round(lossv, 5)}
+        if world > 1:
+            # from the builder's side (one GPU per lease) the N-rank RCCL step had never executed before this run;
+            # the line says what actually ran so that a silently degraded path cannot pass for the production one
+            out["multi_rank_path"] = {"graph_with_collectives": bool(step.use_graph), "backend": a.backend,
+                                      "note": "first hardware execution of the RCCL path happens in the driver's scaling run; "
+                                              "builder-side coverage: 2-rank gloo (CPU + 1 GPU), 1-rank RCCL capture"}
         sys.stderr.write("[bench] timed region done: %.3f ms/step\n" % (dt / a.steps * 1e3)); sys.stderr.flush()
         out["step_roofline"] = step_roofline(a.model if a.model != "dsnetnoCorr" else "dsnet", a.batch * world, a.height, a.width,
                                              dt / a.steps * 1e3, a.dtype)
@@ -350,13 +366,18 @@ def main():
             out["roofline_hbm"] = hbm_kernel_roofline(dtype, a.batch, a.height, a.width)
         if world == 1 and not a.no_secondary and a.model == "minidsnetExt" and not a.no_graph:
             sec = []
-            for name, sb, label in (("dsnet", a.batch, "dsnet = PyTorch port of baseline_SDnet_small_fixed (BASELINE config 2 as literally named)"),
-                                    ("psmnet", 8, "PSMNet(192) stacked hourglass, loss mean L1 x3 (BASELINE config 3, SURVEY 8d batch 8)")):
-                sys.stderr.write("[bench] secondary: %s B=%d\n" % (name, sb)); sys.stderr.flush()
-                ms, lv, gr = time_model(name, dtype, sb, a.height, a.width, a.secondary_steps, 1)
-                sec.append({"workload": "%s, %dx%d, batch %d, %s" % (label, a.width, a.height, sb, "hipGraph" if gr else "eager"),
-                            "value": round(sb / ms * 1e3, 2), "unit": "stereo-pairs/s", "ms_per_step": round(ms, 3), "steps": a.secondary_steps,
-                            "loss": round(lv, 5), "step_roofline": step_roofline(name, sb, a.height, a.width, ms, a.dtype)})
+            f32 = torch.float32
+            for name, sb, sdt, label in (
+                    ("dsnet", a.batch, dtype, "dsnet = PyTorch port of baseline_SDnet_small_fixed (BASELINE config 2 as literally named)"),
+                    ("psmnet", 8, dtype, "PSMNet(192) stacked hourglass, loss mean L1 x3 (BASELINE config 3, SURVEY 8d batch 8)"),
+                    ("minidsnetExt", a.batch, f32, "minidsnetExt, the headline workload on the fp32 path (the arithmetic north_star's 1e-3 "
+                                                   "parity gate is stated for: f32 activations, v_mfma_f32_16x16x4_f32)")):
+                sname = "f32" if sdt == f32 else a.dtype
+                sys.stderr.write("[bench] secondary: %s B=%d %s\n" % (name, sb, sname)); sys.stderr.flush()
+                ms, lv, gr = time_model(name, sdt, sb, a.height, a.width, a.secondary_steps, 1)
+                sec.append({"workload": "%s, %dx%d, batch %d, %s, %s" % (label, a.width, a.height, sb, sname, "hipGraph" if gr else "eager"),
+                            "dtype": sname, "value": round(sb / ms * 1e3, 2), "unit": "stereo-pairs/s", "ms_per_step": round(ms, 3),
+                            "steps": a.secondary_steps, "loss": round(lv, 5), "step_roofline": step_roofline(name, sb, a.height, a.width, ms, sname)})
             out["secondary"] = sec
         if world == 1 and not a.no_cpu_baseline and a.model == "minidsnetExt":
             out["cpu_baseline"] = cpu_baseline(2, a.height, a.width, a.cpu_steps, a.cpu_threads, a.cpu_warmup)

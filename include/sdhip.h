@@ -352,15 +352,17 @@ int sdhip_l1_loss(const void* pred, const float* target, void* grad, double* los
  * the gradient is the backward pass (nn.Dropout(0.5) of models/aspp.py:79,95).  x/y: dense buffers of n elements. */
 int sdhip_dropout(const void* x, void* y, const long* seed, long layer_id, long n, float p, int dtype, void* stream);
 /* Lovasz-softmax (util/lovasz_losses.py:153-199: classes='present', per_image=False) on
- * softmax(logits) with labels = argmax(target one-hot), as called at losses/multiLosses.py:70-72.  A pixel whose target
- * row has no positive entry is void and removed from the loss (`ignore=19` with the 20th one-hot channel dropped,
- * losses/multiLosses.py:19-21; flatten_probas, util/lovasz_losses.py:202-216).
+ * softmax(logits) with labels = argmax(target one-hot), as called at losses/multiLosses.py:70-72.
+ * ignore_void != 0 (the cityscapes / kitti rule): a pixel whose target row has no positive entry is void and removed
+ * from the loss (`ignore=19` with the 20th one-hot channel dropped, losses/multiLosses.py:19-21; flatten_probas,
+ * util/lovasz_losses.py:202-216).  ignore_void == 0 (roses / garden, `ignore=None`, losses/multiLosses.py:11-17): such a
+ * pixel has label argmax = class 0 and counts.
  * loss += weight * mean_{present c} dot(sort_desc |fg_c - p_c|, lovasz_grad(fg sorted)); grad (if non-NULL) is
  * ACCUMULATED (+=) with the gradient w.r.t. the logits.  workspace: sdhip_lovasz_workspace_bytes(npix, C) bytes. */
 long sdhip_lovasz_workspace_bytes(long npix, int C);
 int sdhip_lovasz_softmax(const void* logits, int ldy, const float* target, int ldt, void* grad, int ldg,
                          double* loss, long npix, int C, float weight, void* workspace, long workspace_bytes,
-                         int dtype, void* stream);
+                         int ignore_void, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * PSMNet pieces (models_psmnet/stackhourglass.py:110-119,138-155; submodule.py:56-64).

@@ -293,6 +293,8 @@ def gen_metrics():
         logits[0, 1, 0, :4] = [0.0, 1.0, -1.0, 1.0]                        # exact 0 / 1 logits exercise the threshold and branch-mask rules
         cls = rng.integers(0, Ct, (B, H, W))
         seg_full = np.eye(Ct, dtype=np.float32)[cls].transpose(0, 3, 1, 2).copy()
+        if name == "roses_emptyrow":
+            seg_full[:, :, ::3, 1::4] = 0.0
         disp = (rng.uniform(0, 8, (B, 1, H, W)) * (rng.uniform(0, 1, (B, 1, H, W)) > (0.3 if mask_invalid else -1))).astype(np.float32)
         if not mask_invalid:
             disp += np.float32(0.1)
@@ -491,7 +493,10 @@ def gen_losses():
     rng = np.random.default_rng(5)
     arrays = {}
     cases = [("roses", "roses", 2, 2, 2, 32, 32, None), ("garden_absent", "garden", 5, 5, 2, 16, 24, 3),
-             ("city", "cityscapes", 19, 20, 2, 24, 32, 7), ("city_allvoid_class", "cityscapes", 19, 20, 1, 8, 8, None)]
+             ("city", "cityscapes", 19, 20, 2, 24, 32, 7), ("city_allvoid_class", "cityscapes", 19, 20, 1, 8, 8, None),
+             # roses target with all-zero rows under `ignore=None`: argmax makes them class 0 and they count (appended last:
+             # the generator's draws for the cases above are unchanged)
+             ("roses_emptyrow", "roses", 2, 2, 2, 16, 16, None)]
     for name, ds, L, Ct, B, H, W, absent in cases:
         logits = rng.normal(0, 2, (B, L, H, W)).astype(np.float32)
         cls = rng.integers(0, Ct, (B, H, W))
@@ -501,6 +506,8 @@ def gen_losses():
             cls[:] = 19                      # only void pixels: the Lovasz term and its gradient are zero
             cls[0, 0, :3] = [1, 1, 4]
         seg_full = np.eye(Ct, dtype=np.float32)[cls].transpose(0, 3, 1, 2).copy()
+        if name == "roses_emptyrow":
+            seg_full[:, :, ::3, 1::4] = 0.0
         disp = (rng.uniform(0, 8, (B, 1, H, W)) * (rng.uniform(0, 1, (B, 1, H, W)) > (0.3 if ds == "cityscapes" else -1))).astype(np.float32)
         disp_pred = (disp + rng.normal(0, 1.0, disp.shape)).astype(np.float32)
         cfg = types.SimpleNamespace(datasetName=ds, segWeight=0, outputType='segDisp')
@@ -523,7 +530,7 @@ def gen_losses():
         arrays["%s.l1.grad" % name] = d.grad.numpy().copy()
         # the Lovasz extension on its own (util/lovasz_losses.py:153-168), all three `classes` modes the function offers
         y = torch.from_numpy(logits.copy())
-        lab = torch.from_numpy(cls.copy())
+        lab = torch.from_numpy(seg_full.argmax(1))      # == cls, except where a one-hot row was cleared (roses_emptyrow)
         ign = None if ds in ("roses", "garden") else 19
         arrays["%s.lovasz_present" % name] = np.float64(float(LV.lovasz_softmax(F.softmax(y, 1), lab, ignore=ign)))
         arrays.update({"%s.logits" % name: logits, "%s.seg_full" % name: seg_full, "%s.disp" % name: disp,
@@ -535,7 +542,7 @@ def gen_losses():
         y1 = torch.from_numpy(logits).requires_grad_(True)
         dd = torch.from_numpy(disp_pred).requires_grad_(True)
         zero = torch.zeros_like(y1)
-        mine = train_loss_ref(y1, dd, y1, seg_t, torch.from_numpy(disp), True, ds == "cityscapes")   # CE counted twice
+        mine = train_loss_ref(y1, dd, y1, seg_t, torch.from_numpy(disp), True, ds == "cityscapes", ds == "cityscapes")   # CE counted twice
         want = 2 * arrays["%s.ce.loss" % name] + arrays["%s.lovasz.loss" % name] + arrays["%s.l1.loss" % name]
         assert abs(float(mine) - want) < 1e-5 * max(1.0, abs(want)), (name, float(mine), want)
         mine.backward()
@@ -640,7 +647,7 @@ def gen_cfg5():
         seg = F.one_hot(cls, 20).permute(0, 3, 1, 2).float()[:, :19].contiguous()
         disp = rand_input(91, "disp", (2, 1, 256, 256), 0.0, 8.0) * (rand_input(91, "dmask", (2, 1, 256, 256)) > 0.3).float()
         outs = ref(a, b, pos)
-        loss = train_loss_ref(outs[0], outs[1], outs[2], seg, disp, True, True)
+        loss = train_loss_ref(outs[0], outs[1], outs[2], seg, disp, True, True, True)
         loss.backward()
         for i, name in enumerate(("seg1", "disp", "seg2")):
             arrays.update(flat("%s.eval.%s" % (tag, name), sample(outs[i], 8)))

@@ -70,7 +70,7 @@ SIGNATURES = {
     "sdhip_adam_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
     "sdhip_ce_loss": [_p, _i, _p, _i, _p, _i, _p, _l, _i, _f, _i, _p],
     "sdhip_dropout": [_p, _p, _p, _l, _l, _f, _i, _p],
-    "sdhip_lovasz_softmax": [_p, _i, _p, _i, _p, _i, _p, _l, _i, _f, _p, _l, _i, _p],
+    "sdhip_lovasz_softmax": [_p, _i, _p, _i, _p, _i, _p, _l, _i, _f, _p, _l, _i, _i, _p],
     "sdhip_stuff": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_cost_volume_fwd": [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_cost_volume_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -859,8 +859,14 @@ extern "C" int sdhip_channel_stats(const void* x, int ldx, double* stats, int ld
   SDHIP_CHECK_ARG(x && stats && ldx >= C, "channel_stats: bad pointers/strides");
   hipStream_t s = (hipStream_t)stream;
   if (zero_first) {
-    if (hipMemset2DAsync(stats, sizeof(double) * (size_t)ldc, 0, sizeof(double) * (size_t)C, 2 * (size_t)G * nrep, s) != hipSuccess)
-      SDHIP_FAIL(SDHIP_ERR_LAUNCH, "channel_stats: memset failed");
+    // kernels, not memset nodes (sdhip_common.h): dense replicas in one launch, a strided slice row by row
+    const size_t rows = 2 * (size_t)G * nrep;
+    if (ldc == C) {
+      if (sdhip_zero_async(stats, sizeof(double) * (size_t)C * rows, s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "channel_stats: clear failed");
+    } else {
+      for (size_t r = 0; r < rows; ++r)
+        if (sdhip_zero_async(stats + r * (size_t)ldc, sizeof(double) * (size_t)C, s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "channel_stats: clear failed");
+    }
   }
 #define ARGS(T) (const T*)x, ldx, stats, ldc, nrep, C, npix / G
   if (dtype == SDHIP_F32) {

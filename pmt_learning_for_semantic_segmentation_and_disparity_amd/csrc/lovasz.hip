@@ -8,6 +8,8 @@
 // passes ignore=19): a pixel whose target row has no positive entry is VOID.  Void pixels get the key -1 (every real error
 // is >= 0), so the descending sort parks them behind the nvalid real entries; the Jaccard walk stops at nvalid and they
 // receive no gradient — the same as removing them from the flattened arrays.
+// ignore=None (roses / garden, losses/multiLosses.py:11-17): nothing is void — the label of an all-zero row is argmax = class 0
+// and the pixel counts like any other.  `ignore_void` selects between the two rules.
 #include "sdhip_common.h"
 #include <cstring>
 #include <string.h>
@@ -29,7 +31,7 @@ struct FgFlag {
 template <typename T>
 __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ t, int ldt,
                                                             float* __restrict__ keys, unsigned int* __restrict__ vals,
-                                                            unsigned int* __restrict__ counts, long npix, int C) {
+                                                            unsigned int* __restrict__ counts, long npix, int C, int ignore_void) {
   // per-class pixel counts: LDS histogram per workgroup, one global atomic per class per workgroup (a global atomic per
   // pixel on C addresses serialises: ~10 ms for 1M pixels)
   __shared__ unsigned int hist[64];
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict_
       const float tv = t[p * ldt + c];
       if (tv > tbest) { tbest = tv; label = c; }   // argmax, first maximum wins (torch.argmax)
     }
-    if (!(tbest > 0.f)) {   // void pixel
+    if (ignore_void && !(tbest > 0.f)) {   // void pixel
       for (int c = 0; c < C; ++c) {
         keys[(long)c * npix + p] = -1.f;
         vals[(long)c * npix + p] = (unsigned int)p;
@@ -104,7 +106,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void lovasz_backward_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ t, int ldt,
                                                               const float* __restrict__ gerr, const unsigned int* __restrict__ counts,
                                                               const double* __restrict__ lossc, T* __restrict__ gy, int ldg,
-                                                              double* __restrict__ loss, long npix, int C, float weight) {
+                                                              double* __restrict__ loss, long npix, int C, float weight, int ignore_void) {
   int npres = 0;
   for (int c = 0; c < C; ++c) npres += counts[c] > 0u ? 1 : 0;
   const float w = weight / (float)(npres > 0 ? npres : 1);
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void lovasz_backward_kernel(const T* __restric
       const float tv = t[p * ldt + c];
       if (tv > tbest) { tbest = tv; label = c; }
     }
-    if (!(tbest > 0.f)) continue;   // void pixel: not part of the loss
+    if (ignore_void && !(tbest > 0.f)) continue;   // void pixel: not part of the loss
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += __expf(Elem<T>::ld(yp + c) - mx);
     const float inv = 1.f / se;
@@ -201,7 +203,7 @@ extern "C" long sdhip_lovasz_workspace_bytes(long npix, int C) {
 
 extern "C" int sdhip_lovasz_softmax(const void* logits, int ldy, const float* target, int ldt, void* grad, int ldg,
                                     double* loss, long npix, int C, float weight, void* workspace, long workspace_bytes,
-                                    int dtype, void* stream) {
+                                    int ignore_void, int dtype, void* stream) {
   SDHIP_CHECK_ARG(logits && target && loss && workspace && npix > 0 && C > 0 && ldy >= C && ldt >= C && (!grad || ldg >= C),
                   "lovasz_softmax: bad arguments");
   SDHIP_CHECK_ARG(npix < (1L << 31), "lovasz_softmax: more than 2^31 pixels");
@@ -219,9 +221,9 @@ extern "C" int sdhip_lovasz_softmax(const void* logits, int ldy, const float* ta
   // (a kernel, not hipMemsetAsync: the step is replayed from a hipGraph, and everything in it is kept to kernel nodes)
   if (sdhip_zero_async(ws + L.counts, L.temp - L.counts, s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "lovasz_softmax: clearing the counters failed");
   if (dtype == SDHIP_F32)
-    hipLaunchKernelGGL(lovasz_errors_kernel<float>, grid_for(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, keys_in, vals_in, counts, npix, C);
+    hipLaunchKernelGGL(lovasz_errors_kernel<float>, grid_for(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, keys_in, vals_in, counts, npix, C, ignore_void);
   else
-    hipLaunchKernelGGL(lovasz_errors_kernel<bf16_t>, grid_for(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, keys_in, vals_in, counts, npix, C);
+    hipLaunchKernelGGL(lovasz_errors_kernel<bf16_t>, grid_for(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, keys_in, vals_in, counts, npix, C, ignore_void);
   for (int c = 0; c < C; ++c) {
     size_t tb = L.temp_bytes;
     const size_t o = (size_t)c * npix;
@@ -235,9 +237,9 @@ extern "C" int sdhip_lovasz_softmax(const void* logits, int ldy, const float* ta
   dim3 g2 = grid_for(npix); g2.y = C;
   hipLaunchKernelGGL(lovasz_grad_kernel, g2, dim3(256), 0, s, keys_out, vals_out, cum, counts, gerr, lossc, npix, C);
   if (dtype == SDHIP_F32)
-    hipLaunchKernelGGL(lovasz_backward_kernel<float>, grid_stream(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, gerr, counts, lossc, (float*)grad, ldg, loss, npix, C, weight);
+    hipLaunchKernelGGL(lovasz_backward_kernel<float>, grid_stream(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, gerr, counts, lossc, (float*)grad, ldg, loss, npix, C, weight, ignore_void);
   else
-    hipLaunchKernelGGL(lovasz_backward_kernel<bf16_t>, grid_stream(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, gerr, counts, lossc, (bf16_t*)grad, ldg, loss, npix, C, weight);
+    hipLaunchKernelGGL(lovasz_backward_kernel<bf16_t>, grid_stream(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, gerr, counts, lossc, (bf16_t*)grad, ldg, loss, npix, C, weight, ignore_void);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }

@@ -122,26 +122,26 @@ static inline int sdhip_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // Lovasz class counters then accumulated from replay to replay: tests/diag/gpu_lovasz_graph.py).  Everything the
 // library clears on a stream is therefore cleared by this kernel: a captured step consists of kernel nodes only.
 namespace {
-__global__ __launch_bounds__(256) void sdhip_zero_kernel(unsigned int* __restrict__ p, size_t n4) {
+__global__ __launch_bounds__(256) void sdhip_zero_kernel(unsigned char* __restrict__ p, size_t bytes) {
+  // any alignment, any length: byte head up to the first 16-byte boundary, 16-byte body, byte tail (a 2-byte-aligned bf16
+  // buffer with an odd element count must not fall back to a memset node either)
   const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if ((((uintptr_t)p) & 15) == 0) {
-    u32x4* p16 = reinterpret_cast<u32x4*>(p);
-    const size_t n16 = n4 >> 2;
-    for (size_t j = i; j < n16; j += stride) p16[j] = u32x4{0u, 0u, 0u, 0u};
-    for (size_t j = (n16 << 2) + i; j < n4; j += stride) p[j] = 0u;
-  } else {
-    for (size_t j = i; j < n4; j += stride) p[j] = 0u;
-  }
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t head = (size_t)((16 - (((uintptr_t)p) & 15)) & 15);
+  if (head > bytes) head = bytes;
+  const size_t n16 = (bytes - head) >> 4;
+  const size_t tail0 = head + (n16 << 4);
+  u32x4* p16 = reinterpret_cast<u32x4*>(p + head);
+  for (size_t j = i; j < n16; j += stride) p16[j] = u32x4{0u, 0u, 0u, 0u};
+  if (i < head) p[i] = 0;
+  if (tail0 + i < bytes && i < 16) p[tail0 + i] = 0;
 }
-inline hipError_t sdhip_zero_async(void* ptr, size_t bytes, hipStream_t s) {   // ptr 4-byte aligned, bytes a multiple of 2
+inline hipError_t sdhip_zero_async(void* ptr, size_t bytes, hipStream_t s) {
   if (bytes == 0) return hipSuccess;
-  if ((((uintptr_t)ptr) & 3) || (bytes & 3)) return hipMemsetAsync(ptr, 0, bytes, s);   // (never on the hot path: all buffers are >= 4-byte multiples)
-  const size_t n4 = bytes >> 2;
-  size_t blocks = (n4 / 4 + 255) / 256;
+  size_t blocks = (bytes / 16 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(sdhip_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned int*)ptr, n4);
+  hipLaunchKernelGGL(sdhip_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned char*)ptr, bytes);
   return hipGetLastError();
 }
 }  // namespace

@@ -130,6 +130,7 @@ class StepContext:
         self.unpacks = []        # deferred weight-gradient unpack descriptors of the running step (direct_grads)
         self.unpack_key = None   # the descriptor rows the cached device table was built from
         self.unpack_desc = None
+        self.seed = None         # device-resident dropout seed of the owning TrainStep (rng_seed_tensor)
 
     def join(self):
         """Main stream waits for the side stream (call after backward, before the optimizer), then ONE launch adds every
@@ -1190,7 +1191,7 @@ class _TrainLossFn(torch.autograd.Function):
     three network outputs are produced in the same pass."""
 
     @staticmethod
-    def forward(ctx, seg1, disp, seg2, seg_t, disp_t, use_lovasz, mask_invalid_disp=False):
+    def forward(ctx, seg1, disp, seg2, seg_t, disp_t, use_lovasz, mask_invalid_disp=False, ignore_void=False):
         _require_gpu(seg1, disp, seg2, seg_t, disp_t)
         B, C, H, W = seg1.shape
         npix = B * H * W
@@ -1219,7 +1220,7 @@ class _TrainLossFn(torch.autograd.Function):
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=seg1.device)
                 _lovasz_ws[key] = ws
             call("sdhip_lovasz_softmax", ptr(s2), ld2, ptr(tv), ldt, ptr(grads[1]), C, ptr(loss), npix, C, 1.0, ptr(ws),
-                 ws.numel(), dt, stream_ptr())
+                 ws.numel(), int(ignore_void), dt, stream_ptr())
         total = loss
         ctx.save_for_backward(grads[0], gd, grads[1])
         return total.float()
@@ -1227,14 +1228,17 @@ class _TrainLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g1, gd, g2 = ctx.saved_tensors
-        return g1, gd, g2, None, None, None, None   # d(total)/d(total) is 1 in the training step
+        return g1, gd, g2, None, None, None, None, None   # d(total)/d(total) is 1 in the training step
 
 
-def train_loss(seg1, disp, seg2, seg_target, disp_target, use_lovasz=True, mask_invalid_disp=False):
-    """seg_target: one-hot f32 (B,C,H,W) — an all-zero row marks a void pixel (cityscapes: the 20th channel dropped,
-    losses/multiLosses.py:19-21): zero cross-entropy term, removed from the Lovasz term; disp_target: f32 (B,1,H,W);
-    mask_invalid_disp: disparities <= 0 are invalid (the cityscapes / kitti rule, losses/multiLosses.py:134-141)."""
-    return _TrainLossFn.apply(seg1, disp, seg2, seg_target, disp_target, use_lovasz, mask_invalid_disp)
+def train_loss(seg1, disp, seg2, seg_target, disp_target, use_lovasz=True, mask_invalid_disp=False, ignore_void=False):
+    """seg_target: one-hot f32 (B,C,H,W); disp_target: f32 (B,1,H,W).  The two dataset rules of losses/multiLosses.py are
+    opt-in, both off by default (roses / garden, `ignore=None`, :11-17):
+      ignore_void       — cityscapes / kitti (:19-21, the 20th one-hot channel dropped, `ignore=19`): an all-zero target row
+                          marks a void pixel, removed from the Lovasz term.  Off: its label is argmax = class 0 and it counts.
+                          (Its cross-entropy term is zero under either rule: sum(-t * log_softmax) over a zero row.)
+      mask_invalid_disp — disparities <= 0 are invalid (:134-141)."""
+    return _TrainLossFn.apply(seg1, disp, seg2, seg_target, disp_target, use_lovasz, mask_invalid_disp, ignore_void)
 
 
 # ============================================================================ dropout / global average pool
@@ -1247,6 +1251,9 @@ _RNG_BASE, _RNG_RANK_STRIDE = 0x5DEECE66D, 0x9E3779B97F4A7C15 >> 1
 def rng_seed_tensor(device):
     """Device-resident dropout seed.  train.TrainStep advances it once per step with a device-side add (captured into the
     step's hipGraph, so replays draw new masks); forward and backward of one step read the same value."""
+    c = _ctx[0]
+    if c is not None and c.seed is not None:                  # a TrainStep's own stream (ADVICE r2: steps must not reset each other)
+        return c.seed
     device = torch.device(device)
     if device.type == "cuda" and device.index is None:       # "cuda" and "cuda:0" must name the same tensor: a captured step
         device = torch.device("cuda", torch.cuda.current_device())   # keeps adding to the one it was recorded with
@@ -1255,10 +1262,14 @@ def rng_seed_tensor(device):
     return _rng["seed"]
 
 
+def rng_seed_value(rank=0, base=_RNG_BASE):
+    return (base + rank * _RNG_RANK_STRIDE) & 0x7FFFFFFFFFFFFFFF
+
+
 def rng_reseed(device, rank=0, base=_RNG_BASE):
-    """Restart the dropout stream; ranks of a data-parallel job get disjoint streams (in place: a captured graph keeps
-    reading the same tensor)."""
-    rng_seed_tensor(device).fill_((base + rank * _RNG_RANK_STRIDE) & 0x7FFFFFFFFFFFFFFF)
+    """Restart the dropout stream (the module-level one, or the installed TrainStep's); ranks of a data-parallel job get
+    disjoint streams (in place: a captured graph keeps reading the same tensor)."""
+    rng_seed_tensor(device).fill_(rng_seed_value(rank, base))
 
 
 class _DropoutFn(torch.autograd.Function):

@@ -66,9 +66,12 @@ class TrainStep:
         self.pack_desc = None
         self.steps_done = 0       # optimizer steps actually EXECUTED (eager steps + graph replays; the recording pass of a capture runs nothing)
         self._capture_fault = None   # tests: a callable invoked inside the capture to make it fail
+        self.debug_graph = False     # tests: keep the captured hipGraph inspectable (graph.debug_dump)
         # dropout streams differ per rank (the reference's ranks draw from independently seeded generators) and advance
         # once per step on the device, so that graph replays see new masks (ops.rng_seed_tensor)
-        ops.rng_reseed(self.flat_p.device, rank=_rank_of(process_group) if world_size > 1 else 0)
+        # (the tensor belongs to this step's context: creating a second TrainStep does not restart the first one's stream)
+        self.ctx.seed = torch.full((1,), ops.rng_seed_value(_rank_of(process_group) if world_size > 1 else 0), dtype=torch.int64,
+                                   device=self.flat_p.device)
 
     # -- pieces ---------------------------------------------------------------------------------
     def _arm(self):
@@ -76,6 +79,13 @@ class TrainStep:
         launch, switch parameter gradients to direct accumulation into the flat buffer."""
         self.ctx.allocate_arena()
         rows = ops.pack_descriptors(self.dtype, owners=self.model.parameters())   # this model's weights only
+        # The table is replayed for the lifetime of the step (inside the hipGraph): every source must be a slice of THIS
+        # step's flat parameter buffer — a row of anything else would read freed memory once its owner is gone (the fault
+        # of round 2, tests/test_train.py::test_pack_table_holds_only_the_steps_own_weights)
+        lo, hi = self.flat_p.data_ptr(), self.flat_p.data_ptr() + 4 * self.flat_p.numel()
+        for r in rows:
+            if not (lo <= r[0] < hi):
+                raise _lib.SdhipError("weight-pack table holds a source outside this step's parameter buffer")
         self.pack_desc = torch.tensor(rows, dtype=torch.int64, device=self.flat_p.device) if rows else None
         self.ctx.frozen_pack = self.pack_desc is not None
         self.ctx.direct_grads = True
@@ -123,7 +133,7 @@ class TrainStep:
             torch._foreach_add_(self.nbt_tensors, self.nbt_incs)   # BatchNorm.num_batches_tracked, one launch
         # next step draws new dropout masks.  A device-side add AFTER the backward pass (which regenerates this step's
         # masks from the same seed): captured into the graph, so every replay advances it too.
-        ops.rng_seed_tensor(self.flat_p.device).add_(1)
+        self.ctx.seed.add_(1)
         if not torch.cuda.is_current_stream_capturing():
             self.steps_done += 1
         return loss
@@ -149,6 +159,8 @@ class TrainStep:
         gc.collect()
         torch.cuda.empty_cache()
         graph = torch.cuda.CUDAGraph()
+        if self.debug_graph:
+            graph.enable_debug_mode()            # keeps the hipGraph for graph.debug_dump() (node inventory tests)
         # data parallel: the RCCL watchdog thread polls events while we capture; thread-local capture errors keep its
         # (legal) calls from invalidating the capture of this thread
         mode = "thread_local" if self.world_size > 1 else "global"
@@ -158,6 +170,7 @@ class TrainStep:
         # hipErrorStreamCaptureInvalidated).  Here a failure ends the capture explicitly (sdhip_abort_capture).
         gc_was_on = gc.isenabled()
         gc.disable()
+        self._gen_state = self._torch_generator_state()    # restored exactly should the capture fail (_abandon_capture)
         try:
             with torch.cuda.stream(cap):
                 graph.capture_begin(capture_error_mode=mode)
@@ -195,6 +208,13 @@ class TrainStep:
             pass
         del graph
 
+    def _torch_generator_state(self):
+        try:
+            dev = self.flat_p.device
+            return torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()].get_state()
+        except BaseException:
+            return None
+
     def _abandon_capture(self):
         """A capture that raised recorded launches but executed none: device state (parameters, moments, running
         statistics, dropout seed) is that of the last eager warm-up step.  Only host-side bookkeeping of the half-recorded
@@ -203,12 +223,16 @@ class TrainStep:
         torch.cuda.synchronize()               # raises if the process could not be brought back: nothing can run then
         # capture_begin put torch's default CUDA generator into capture mode and only a completed capture_end takes it out
         # again ("Offset increment outside graph capture" on the next torch.randn(device='cuda')): give the generator a
-        # fresh, non-capturing state object with the same seed
+        # fresh, non-capturing state object carrying EXACTLY the seed and offset it had before the capture began — later
+        # torch CUDA draws continue the stream instead of replaying it from its start
         try:
             dev = self.flat_p.device
             gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
             fresh = torch.Generator(device=dev)
-            fresh.manual_seed(gen.initial_seed())
+            if getattr(self, "_gen_state", None) is not None:
+                fresh.set_state(self._gen_state)
+            else:
+                fresh.manual_seed(gen.initial_seed())
             gen.graphsafe_set_state(fresh.graphsafe_get_state())
         except BaseException as e:
             import sys

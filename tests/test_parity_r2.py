@@ -19,7 +19,7 @@ from oracle.losses_ref import lovasz_softmax_onehot, train_loss_ref
 from test_nets import _check, _net_inputs, train_loss
 
 GDIR = os.path.join(os.path.dirname(__file__), "golden")
-LOSS_CASES = ["roses", "garden_absent", "city", "city_allvoid_class"]
+LOSS_CASES = ["roses", "garden_absent", "city", "city_allvoid_class", "roses_emptyrow"]
 
 
 def _loss_case(gold, name):
@@ -36,13 +36,13 @@ def test_oracle_losses_match_reference(name):
     gold = np.load(os.path.join(GDIR, "losses.npz"))
     L, ds, logits, seg_t, disp, disp_pred = _loss_case(gold, name)
     y = logits.clone().requires_grad_(True)
-    lv = lovasz_softmax_onehot(y, seg_t)
+    lv = lovasz_softmax_onehot(y, seg_t, ds == "cityscapes")
     assert abs(float(lv) - float(gold[name + ".lovasz.loss"])) < 1e-5
     assert abs(float(lv) - float(gold[name + ".lovasz_present"])) < 1e-5
     lv.backward()
     assert float((y.grad - torch.from_numpy(gold[name + ".lovasz.grad"])).abs().max()) < 1e-6
     y1, y2, d = (t.clone().requires_grad_(True) for t in (logits, logits, disp_pred))
-    tot = train_loss_ref(y1, d, y2, seg_t, disp, True, ds == "cityscapes")
+    tot = train_loss_ref(y1, d, y2, seg_t, disp, True, ds == "cityscapes", ds == "cityscapes")
     want = float(gold[name + ".ce.loss"]) + float(gold[name + ".ce_lovasz.loss"]) + float(gold[name + ".l1.loss"])
     assert abs(float(tot) - want) < 1e-5 * max(1.0, want)
     tot.backward()
@@ -103,7 +103,7 @@ def test_oracle_cfg5_matches_golden(tag):
         outs = m(a, b, pos)
     for i, name in enumerate(("seg1", "disp", "seg2")):
         _check(gold, "%s.eval.%s" % (tag, name), outs[i], 2e-4)
-    loss = train_loss_ref(outs[0], outs[1], outs[2], seg, disp, True, True)
+    loss = train_loss_ref(outs[0], outs[1], outs[2], seg, disp, True, True, True)
     assert abs(float(loss) - float(gold[tag + ".eval.loss"])) < 1e-3
 
 
@@ -145,7 +145,7 @@ def test_hip_losses_match_reference(name):
     gold = np.load(os.path.join(GDIR, "losses.npz"))
     L, ds, logits, seg_t, disp, disp_pred = _loss_case(gold, name)
     y1, y2, d = (t.cuda().requires_grad_(True) for t in (logits, logits, disp_pred))
-    tot = ops.train_loss(y1, d, y2, seg_t.cuda(), disp.cuda(), True, ds == "cityscapes")
+    tot = ops.train_loss(y1, d, y2, seg_t.cuda(), disp.cuda(), True, ds == "cityscapes", ds == "cityscapes")
     tot.backward()
     want = float(gold[name + ".ce.loss"]) + float(gold[name + ".ce_lovasz.loss"]) + float(gold[name + ".l1.loss"])
     assert abs(float(tot) - want) < 1e-5 * max(1.0, want), (float(tot), want)
@@ -154,7 +154,7 @@ def test_hip_losses_match_reference(name):
     assert float((d.grad.cpu() - torch.from_numpy(gold[name + ".l1.grad"])).abs().max()) < 1e-7
     # without the Lovasz term the second head carries the plain CE gradient
     y1, y2, d = (t.cuda().requires_grad_(True) for t in (logits, logits, disp_pred))
-    ops.train_loss(y1, d, y2, seg_t.cuda(), disp.cuda(), False, ds == "cityscapes").backward()
+    ops.train_loss(y1, d, y2, seg_t.cuda(), disp.cuda(), False, ds == "cityscapes", ds == "cityscapes").backward()
     assert float((y2.grad.cpu() - torch.from_numpy(gold[name + ".ce.grad"])).abs().max()) < 1e-6
 
 
@@ -198,7 +198,7 @@ def test_hip_cfg5_matches_golden(tag):
     gold = np.load(os.path.join(GDIR, "cfg5.npz"))
     m, a, b, pos, seg, disp = _cfg5_case(gold, tag, N.minidsnetExt, "cuda")
     outs = m(a, b, pos)
-    loss = ops.train_loss(outs[0], outs[1], outs[2], seg, disp, True, True)
+    loss = ops.train_loss(outs[0], outs[1], outs[2], seg, disp, True, True, True)
     loss.backward()
     for i, name in enumerate(("seg1", "disp", "seg2")):
         _check(gold, "%s.eval.%s" % (tag, name), outs[i], 1e-3)
@@ -237,7 +237,7 @@ def test_hip_large_config_properties(B, H, W, aspp):
     assert tuple(outs[0].shape) == (B, 19, H, W) and tuple(outs[1].shape) == (B, 1, H, W) and tuple(outs[2].shape) == (B, 19, H, W)
     for o in outs[:3]:
         assert torch.isfinite(o.float()).all()
-    loss = ops.train_loss(outs[0], outs[1], outs[2], seg, disp, True, True)
+    loss = ops.train_loss(outs[0], outs[1], outs[2], seg, disp, True, True, True)
     loss.backward()
     assert torch.isfinite(loss).all()
     bad = [k for k, p in m.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]

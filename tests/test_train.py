@@ -145,7 +145,8 @@ def test_dropout_seed_advances_every_step(graph):
     from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
     batch = synthetic_batch(2, 256, 256)
     ts = TrainStep(_aspp_model(), dtype=torch.float32, use_graph=graph, lr=0.0)   # lr 0: only the masks change the loss
-    seed = ops.rng_seed_tensor("cuda")
+    seed = ts.ctx.seed                       # the step's own device-resident seed
+    other = TrainStep(_aspp_model(), dtype=torch.float32, use_graph=False, lr=0.0)   # a second step must not restart the first one's stream
     seeds, losses = [], []
     for _ in range(5):
         losses.append(float(ts(*batch)))
@@ -198,6 +199,67 @@ def test_failed_capture_falls_back_to_a_consistent_eager_step(how, capfd):
     err = capfd.readouterr().err
     assert "continuing WITHOUT a graph" in err and "could not" not in err, err
     torch.randn(8, device="cuda")                # torch's own CUDA generator is usable again (it was in capture mode)
+
+
+@pytest.mark.gpu
+def test_failed_capture_keeps_torchs_cuda_random_stream():
+    """After a failed capture torch's default CUDA generator continues where it was before the capture began (it
+    used to be re-seeded at offset 0, so later draws replayed the stream from its start)."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    batch = synthetic_batch(2, 256, 256)
+    ts = TrainStep(_model(), dtype=torch.float32, use_graph=True, lr=1e-4)
+    torch.manual_seed(77)
+    first = torch.rand(1000, device="cuda")      # consumes part of the stream: the state at capture time is NOT the start
+    want_next = None
+    st = torch.cuda.get_rng_state()
+    want_next = torch.rand(1000, device="cuda")
+    torch.cuda.set_rng_state(st)
+
+    def boom():
+        raise RuntimeError("injected capture failure")
+    ts._capture_fault = boom
+    ts(*batch)
+    ops.set_step_context(None)
+    got = torch.rand(1000, device="cuda")
+    assert torch.equal(got, want_next) and not torch.equal(got, first)
+
+
+@pytest.mark.gpu
+def test_captured_step_consists_of_kernel_nodes_only(tmp_path):
+    """No memset / memcpy node inside the captured training step: hipMemsetAsync nodes were observed to stop clearing after
+    unrelated allocations between replays on ROCm 7.2 (sdhip_common.h), so every clear is a kernel — the Lovasz counters,
+    DenseNet's incoming-statistics replicas (sdhip_channel_stats), odd-sized bf16 buffers included."""
+    import re
+    import collections
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    batch = synthetic_batch(2, 256, 256)
+    ts = TrainStep(_model(), dtype=torch.bfloat16, use_graph=True, lr=1e-4)
+    ts.debug_graph = True
+    ts(*batch)
+    ops.set_step_context(None)
+    assert ts.graph is not None
+    dot = str(tmp_path / "step.dot")
+    ts.graph.debug_dump(dot)
+    txt = open(dot).read()
+    labels = re.findall(r'label="([^"]*)"', txt)
+    assert len(labels) > 500, len(labels)
+    bad = [l for l in labels if re.search(r"memset|memcpy", l, re.I)]
+    assert not bad, collections.Counter(b.split("\\n")[0][:60] for b in bad)
+
+
+@pytest.mark.gpu
+def test_zero_kernel_any_alignment():
+    """sdhip_zero_async clears buffers of any alignment and length with a kernel (an odd bf16 element count used to fall back
+    to hipMemsetAsync): exercised through the HANet row-pool backward, which clears its gradient map first."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    for C, H, W in ((3, 5, 7), (1, 9, 3), (8, 4, 4)):
+        x = torch.randn(1, C, H, W, device="cuda").bfloat16().requires_grad_(True)
+        y = ops.rowpool_max(x, 2)
+        y.float().sum().backward()
+        g = x.grad.float()
+        assert torch.isfinite(g).all() and float(g.sum()) == float(C * 2)     # one winner per (channel, output row)
 
 
 @pytest.mark.gpu

@@ -51,6 +51,9 @@ void sdhip_diag_reload(void);
  * capture was still open, 0 if none was, < 0 if the stream cannot be brought back.  Host-side recovery for the training
  * step's hipGraph (the reference has no graph capture; its counterpart is simply running the step eagerly). */
 int sdhip_abort_capture(void* stream);
+/* Node inventory of a captured step: graph = hipGraph_t; counts[0..3] = kernel, memset, memcpy, other nodes.  Returns the
+ * total node count (< 0: error).  The library keeps a captured step to kernel nodes (sdhip_zero_async); tests assert it. */
+int sdhip_graph_node_counts(void* graph, int* counts);
 
 /* ---------------------------------------------------------------------------
  * Spatial correlation sampler  (third-party op `SpatialCorrelationSampler`,
@@ -198,6 +201,17 @@ int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* d
                        int kh, int kw, int stride, int dil, int pad_t, int pad_l,
                        int D, int Do, int kd, int sd, int pad_d,
                        int in_relu, int groups, int prezeroed, int dtype, void* stream);
+/* The weight gradients of n layers in as few launches as possible: layers that run on the same kernel instantiation share
+ * ONE grid (<= 16 layers per grid; the layer table travels in the kernel arguments, so a captured step needs no device
+ * table).  items: HOST array, fields as the arguments of sdhip_conv2d_wgrad; every dw_packed / dbias must already be zero
+ * (prezeroed semantics).  Results equal n calls of sdhip_conv2d_wgrad up to the order of the f32 atomic adds.  Nothing in
+ * a training step reads a weight gradient before the optimizer (torch_implementation.py:389,724), so the step queues its
+ * ~200 per-layer launches and issues them here after the backward pass (ops.StepContext.join). */
+typedef struct SdhipWgradItem {
+  const void* x; const void* dy; float* dw_packed; float* dbias; const float* in_scale; const float* in_shift;
+  int B, H, W, Cin, ldx, Ho, Wo, Cout, lddy, kh, kw, stride, dil, pad_t, pad_l, D, Do, kd, sd, pad_d, in_relu, groups;
+} SdhipWgradItem;
+int sdhip_conv2d_wgrad_group(const SdhipWgradItem* items, int n, int dtype, void* stream);
 
 /* 1x1 convolution (+ bias, + activation) over the channel concatenation [x0 | x1] without materialising it; segment i is
  * read at pixel (h >> us_i, w >> us_i) of a (B, c_i, H >> us_i, W >> us_i) map, i.e. nearest-neighbour upsampled by

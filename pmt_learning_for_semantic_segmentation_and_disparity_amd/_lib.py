@@ -43,6 +43,7 @@ SIGNATURES = {
     "sdhip_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 27 + [_p],
     "sdhip_conv2d_fwd_phase": [_p, _p, _p, _p, _i, _i] + [_i] * 16 + [_p],
     "sdhip_conv2d_wgrad": [_p, _p, _p, _p, _p, _p] + [_i] * 24 + [_p],
+    "sdhip_conv2d_wgrad_group": [_p, _i, _i, _p],
     "sdhip_conv1x1_cat_fwd": [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_conv_pack_batch": [_p, _i, _i, _p],
     "sdhip_conv_unpack_batch": [_p, _i, _i, _p],
@@ -104,6 +105,13 @@ for _name, _args in SIGNATURES.items():
     _fn.restype = _i
 
 
+class WgradItem(ctypes.Structure):
+    """SdhipWgradItem of include/sdhip.h."""
+    _fields_ = [(n, _p) for n in ("x", "dy", "dw_packed", "dbias", "in_scale", "in_shift")] + \
+               [(n, _i) for n in ("B", "H", "W", "Cin", "ldx", "Ho", "Wo", "Cout", "lddy", "kh", "kw", "stride", "dil", "pad_t", "pad_l",
+                                  "D", "Do", "kd", "sd", "pad_d", "in_relu", "groups")]
+
+
 def lovasz_workspace_bytes(npix, C):
     return _lib.sdhip_lovasz_workspace_bytes(npix, C)
 
@@ -115,6 +123,19 @@ def packed_elems(M, K, T, dt):
 _lib.sdhip_diag_reload.restype = None
 _lib.sdhip_abort_capture.argtypes = [_p]
 _lib.sdhip_abort_capture.restype = _i
+
+
+_lib.sdhip_graph_node_counts.argtypes = [_p, ctypes.POINTER(_i)]
+_lib.sdhip_graph_node_counts.restype = _i
+
+
+def graph_node_counts(graph):
+    """{kernel, memset, memcpy, other, total} of a torch.cuda.CUDAGraph created with keep_graph=True."""
+    c = (_i * 4)()
+    n = _lib.sdhip_graph_node_counts(ctypes.c_void_p(graph.raw_cuda_graph()), c)
+    if n < 0:
+        raise SdhipError("sdhip_graph_node_counts failed: %s" % _lib.sdhip_last_error().decode())
+    return {"kernel": c[0], "memset": c[1], "memcpy": c[2], "other": c[3], "total": n}
 
 
 def abort_capture(stream):
@@ -142,6 +163,7 @@ def _diag_switch(name):
 DIAG_NO_FUSED_BN = bool(_diag_switch("SDHIP_DIAG_NO_FUSED_BN"))
 DIAG_NO_SIDE = bool(_diag_switch("SDHIP_DIAG_NO_SIDE"))
 DIAG_NO_GRAD_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_GRAD_SLOTS"))
+DIAG_NO_WGRAD_GROUP = bool(_diag_switch("SDHIP_DIAG_NO_WGRAD_GROUP"))
 DIAG_NO_BN_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_BN_SLOTS"))
 TUNE_FUSE1_MAX_PIX = int(_diag_switch("SDHIP_TUNE_FUSE1_MAX_PIX") or 32768)
 TUNE_PRO_MAX_PIX = int(_diag_switch("SDHIP_TUNE_PRO_MAX_PIX") or 32768)

@@ -18,6 +18,8 @@
 #include "conv_common.h"
 #include "conv_wgrad_fast.h"
 #include "conv_thin.h"
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -389,13 +391,15 @@ extern "C" int sdhip_conv_unpack_wgrad(const float* acc, float* grad, int M, int
   return SDHIP_OK;
 }
 
-extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* dbias,
-                                  const float* in_scale, const float* in_shift,
-                                  int B, int H, int W, int Cin, int ldx,
-                                  int Ho, int Wo, int Cout, int lddy,
-                                  int kh, int kw, int stride, int dil, int pad_t, int pad_l,
-                                  int D, int Do, int kd, int sd, int pad_d,
-                                  int in_relu, int groups, int prezeroed, int dtype, void* stream) {
+// One layer.  plan == nullptr: launch now.  plan != nullptr: a layer of the bf16 fast path is only PLANNED (*planned = true,
+// nothing launched) so that the caller can group it with others; every other path launches as usual.
+static int wgrad_one(const void* x, const void* dy, float* dw_packed, float* dbias,
+                     const float* in_scale, const float* in_shift,
+                     int B, int H, int W, int Cin, int ldx,
+                     int Ho, int Wo, int Cout, int lddy,
+                     int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                     int D, int Do, int kd, int sd, int pad_d,
+                     int in_relu, int groups, int prezeroed, int dtype, void* stream, WgfPlan* plan, bool* planned) {
   SDHIP_CHECK_ARG(x && dy && dw_packed, "conv2d_wgrad: null pointer");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "conv2d_wgrad: unknown dtype %d", dtype);
   SDHIP_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_wgrad: empty tensor");
@@ -482,15 +486,137 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
       WgfArgs g = f;
       g.qb = a.nq >= 3 ? 4 : 2; g.qsh = g.qb == 4 ? 2 : 1;
       g.kh = 1; g.kw = g.qb; g.tpb = g.qb; g.ntg = 1; g.nq = sdhip_cdiv(a.nq, g.qb);
-      const int rc = in_scale ? launch_wgf_packed<false>(g, s) : launch_wgf_packed<true>(g, s);
-      if (rc != 1) return rc;
+      const int rc = in_scale ? launch_wgf_packed<false>(g, s, plan) : launch_wgf_packed<true>(g, s, plan);
+      if (rc != 1) { if (plan && rc == SDHIP_OK) *planned = true; return rc; }
     }
     // MB = 32 regroups the taps over two wave groups: the tap grouping must match the instantiation (see launch_wgf_taps)
-    const int rc = in_scale ? launch_wgf_taps<false>(f, T, s) : launch_wgf_taps<true>(f, T, s);
-    if (rc != 1) return rc;   // 1: no tile fits LDS -> general kernel below
+    const int rc = in_scale ? launch_wgf_taps<false>(f, T, s, plan) : launch_wgf_taps<true>(f, T, s, plan);
+    if (rc != 1) { if (plan && rc == SDHIP_OK) *planned = true; return rc; }   // 1: no tile fits LDS -> general kernel below
   }
   const bool wide = Wo >= 24;
   // bf16, 25 taps: 25 x (64 x 64) partial sums do not fit 8 waves' registers -> 32 output channels per workgroup
   if (dtype == SDHIP_BF16) return maxt == 9 ? launch_tile<bf16_t, 9, 64>(a, wide, s) : launch_tile<bf16_t, 25, 32>(a, wide, s);
   return maxt == 9 ? launch_tile<float, 9, 32>(a, wide, s) : launch_tile<float, 25, 32>(a, wide, s);
+}
+
+extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* dbias,
+                                  const float* in_scale, const float* in_shift,
+                                  int B, int H, int W, int Cin, int ldx,
+                                  int Ho, int Wo, int Cout, int lddy,
+                                  int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                                  int D, int Do, int kd, int sd, int pad_d,
+                                  int in_relu, int groups, int prezeroed, int dtype, void* stream) {
+  return wgrad_one(x, dy, dw_packed, dbias, in_scale, in_shift, B, H, W, Cin, ldx, Ho, Wo, Cout, lddy, kh, kw, stride, dil, pad_t, pad_l,
+                   D, Do, kd, sd, pad_d, in_relu, groups, prezeroed, dtype, stream, nullptr, nullptr);
+}
+
+namespace {
+
+// One grid for `k` (<= kWgfGroupMax) planned layers of one instantiation.  Tile shares per layer: every workgroup should
+// sweep for about the same time tau; tau is chosen by a sweep over the cost model of plan_wgf (sweep time per tile, closing
+// atomics per workgroup at the chip-wide atomic rate) against the number of workgroup slots.
+int launch_wgf_group(std::vector<WgfPlan>& pls, size_t lo, size_t hi, hipStream_t s) {
+  const int k = (int)(hi - lo);
+  if (k == 1) return launch_wgf_plan(pls[lo], s);
+  size_t lds = 0;
+  int occ = 2;
+  for (size_t i = lo; i < hi; ++i) { if (pls[i].lds > lds) lds = pls[i].lds; if (pls[i].occ < occ) occ = pls[i].occ; }
+  if (2 * lds > 160 * 1024) occ = 1;
+  const int slots = 256 * occ;
+  // Tile shares: for 1..4 rounds of `slots` workgroups, the smallest sweep time tau per workgroup whose shares fit the
+  // budget (bisection), then the candidate with the best modelled time.  The grid must not spill a few workgroups past a
+  // round: with uniform sweep times, 288 workgroups on 256 slots take two rounds (measured: 17 full-resolution layers in
+  // one grid 1.33 ms against 0.82 ms launched one by one, before this rule).
+  double best = 1e30;
+  int best_gx[kWgfGroupMax];
+  auto shares = [&](double tau, int* gxs, double& tmax, double& atom) {
+    long nwg = 0;
+    tmax = 0.; atom = 0.;
+    for (int i = 0; i < k; ++i) {
+      const WgfPlan& p = pls[lo + i];
+      int gx = (int)ceil(p.ntiles * p.t_tile_us / tau);
+      const int cap = sdhip_cdiv(p.ntiles, 2);             // at least two tiles per workgroup: the pipeline overlaps them
+      if (gx > cap) gx = cap;
+      if (gx < 1) gx = 1;
+      const double per = sdhip_cdiv(p.ntiles, gx) * p.t_tile_us + 2.5;   // + start-up and flush latency of a workgroup
+      if (per > tmax) tmax = per;
+      atom += (double)gx * p.gy * p.flush_us;
+      gxs[i] = gx;
+      nwg += (long)gx * p.gy;
+    }
+    return nwg;
+  };
+  for (int rounds = 1; rounds <= 4; ++rounds) {
+    const long budget = (long)slots * rounds;
+    double tl = 0.05, th = 1e5, tmax, atom;
+    int gxs[kWgfGroupMax];
+    for (int it = 0; it < 48; ++it) {
+      const double tm = sqrt(tl * th);
+      if (shares(tm, gxs, tmax, atom) > budget) tl = tm; else th = tm;
+    }
+    const long nwg = shares(th, gxs, tmax, atom);
+    const double t = (double)((nwg + slots - 1) / slots) * tmax + atom;
+    if (t < best) { best = t; for (int i = 0; i < k; ++i) best_gx[i] = gxs[i]; }
+  }
+  // longest workgroups first: the tail of the grid is made of short ones
+  int order[kWgfGroupMax];
+  for (int i = 0; i < k; ++i) order[i] = i;
+  std::sort(order, order + k, [&](int a, int b) {
+    const double ta = sdhip_cdiv(pls[lo + a].ntiles, best_gx[a]) * pls[lo + a].t_tile_us;
+    const double tb = sdhip_cdiv(pls[lo + b].ntiles, best_gx[b]) * pls[lo + b].t_tile_us;
+    return ta > tb;
+  });
+  WgfGroup g = WgfGroup();
+  g.n = k;
+  int wg = 0;
+  for (int j = 0; j < k; ++j) {
+    const int i = order[j];
+    g.wg0[j] = wg;
+    g.gx[j] = best_gx[i];
+    g.L[j] = pls[lo + i].a;
+    wg += best_gx[i] * pls[lo + i].gy;
+  }
+  for (int j = k; j <= kWgfGroupMax; ++j) g.wg0[j] = wg;
+  void* args[] = {&g};
+  if (hipLaunchKernel(pls[lo].group, dim3(wg), dim3(512), args, lds, s) != hipSuccess)
+    SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad_group: launch failed: %s", hipGetErrorString(hipGetLastError()));
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int sdhip_conv2d_wgrad_group(const SdhipWgradItem* items, int n, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(items && n > 0, "conv2d_wgrad_group: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<WgfPlan> plans;
+  plans.reserve(n);
+  for (int i = 0; i < n; ++i) {
+    const SdhipWgradItem& it = items[i];
+    WgfPlan pl;
+    bool planned = false;
+    const int rc = wgrad_one(it.x, it.dy, it.dw_packed, it.dbias, it.in_scale, it.in_shift, it.B, it.H, it.W, it.Cin, it.ldx, it.Ho, it.Wo,
+                             it.Cout, it.lddy, it.kh, it.kw, it.stride, it.dil, it.pad_t, it.pad_l, it.D, it.Do, it.kd, it.sd, it.pad_d,
+                             it.in_relu, it.groups, 1, dtype, stream, &pl, &planned);
+    if (rc != SDHIP_OK) return rc;
+    if (planned) plans.push_back(pl);
+  }
+  // buckets = instantiations, in order of first appearance; <= kWgfGroupMax layers per grid
+  std::vector<char> done(plans.size(), 0);
+  std::vector<WgfPlan> bucket;
+  for (size_t i = 0; i < plans.size(); ++i) {
+    if (done[i]) continue;
+    bucket.clear();
+    for (size_t j = i; j < plans.size(); ++j)
+      if (!done[j] && plans[j].group == plans[i].group) { bucket.push_back(plans[j]); done[j] = 1; }
+    // even chunks (24 layers -> 12 + 12, not 16 + 8)
+    const size_t nchunk = (bucket.size() + kWgfGroupMax - 1) / kWgfGroupMax;
+    const size_t per = (bucket.size() + nchunk - 1) / nchunk;
+    for (size_t lo = 0; lo < bucket.size(); lo += per) {
+      const size_t hi = lo + per < bucket.size() ? lo + per : bucket.size();
+      const int rc = launch_wgf_group(bucket, lo, hi, s);
+      if (rc != SDHIP_OK) return rc;
+    }
+  }
+  return SDHIP_OK;
 }

@@ -63,8 +63,11 @@ __device__ __forceinline__ u32x4 tr_pair(const unsigned char* lo, const unsigned
 // CIT: input-channel tiles across waves.  4 = a whole 64-channel chunk; 2 = layers with <= 32 input channels (PSMNet's 3-D
 // convolutions, the 32-channel Conv2DownUp blocks): the two tiles that would multiply zero channels are not computed — the
 // freed factor 2 goes to the tap split, so a wave carries half the accumulators, MFMAs and fragment reads per tile.
-template <int TH, int TW, int MAXT, int MB, bool DMAX, int CIT = 4>
-__global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
+// (bx, gdx, by) = the workgroup's position: tile share bx of gdx, and the (cout block, depth tap, chunk, tap group) index by.
+// A stand-alone launch passes blockIdx / gridDim; the grouped launch (wgrad_fast_group_kernel) passes the position inside
+// the layer the workgroup was assigned to.
+template <int TH, int TW, int MAXT, int MB, bool DMAX, int CIT>
+__device__ __forceinline__ void wgrad_fast_body(const WgfArgs& p, const int bx, const int gdx, int by) {
   typedef bf16_t T;
   constexpr int V = 8, CK = 64, RB = 128;
   constexpr int NCO = 2;                     // output-channel MFMA tiles per wave
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   const int sbytes = xbytes + ybytes;        // one stage buffer: [X halo][dY tile]
   const int T_ = p.kh * p.kw;
 
-  int by = blockIdx.y;                       // -> (output-channel block, depth tap, channel chunk, tap group)
+  // by -> (output-channel block, depth tap, channel chunk, tap group)
   const int tgi = by % p.ntg; by /= p.ntg;
   const int q = by % p.nq; by /= p.nq;
   const int kdi = by % p.kd;
@@ -177,15 +180,15 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
 
   float psc[V], psf[V];                      // prologue coefficients of the lane's 8 channels (per tile: the group may change)
 
-  // Tile walk without divisions: (image, tile row, tile column) of the NEXT tile to issue advance by gridDim.x tiles.
+  // Tile walk without divisions: (image, tile row, tile column) of the NEXT tile to issue advance by gdx tiles.
   int n_img, n_ty, n_tx;
   {
-    const int t0i = blockIdx.x;
+    const int t0i = bx;
     n_img = t0i / (tiles_h * tiles_w);
     const int tr = t0i - n_img * tiles_h * tiles_w;
     n_ty = tr / tiles_w; n_tx = tr - n_ty * tiles_w;
   }
-  const int step_tx = (int)gridDim.x % tiles_w, step_r = (int)gridDim.x / tiles_w;
+  const int step_tx = gdx % tiles_w, step_r = gdx / tiles_w;
   const int step_ty = step_r % tiles_h, step_img = step_r / tiles_h;
 
   // Per-lane source offsets of an INTERIOR tile (no padding, no ragged edge): tile base + constant offset per round.
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
   };
 
   // ---- sweep ----
-  const int ntl = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // this workgroup's tiles
+  const int ntl = (ntiles - bx + gdx - 1) / gdx;   // this workgroup's tiles
   if constexpr (DMAX) {
     if (ntl > 0) issue(smem);
     for (int it = 0; it < ntl; ++it) {
@@ -435,8 +438,50 @@ __global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
 }
 
 template <int TH, int TW, int MAXT, int MB, bool DMAX, int CIT = 4>
-int launch_wgf(const WgfArgs& a, hipStream_t s) {
+__global__ __launch_bounds__(512) void wgrad_fast_kernel(const WgfArgs p) {
+  wgrad_fast_body<TH, TW, MAXT, MB, DMAX, CIT>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+}
+
+// ---- grouped launch: the weight gradients of SEVERAL layers in one grid -----------------------------------------------
+// Nothing downstream of a weight gradient runs before the optimizer, so the step queues them and launches every bucket of
+// layers that share an instantiation as ONE grid (sdhip_conv2d_wgrad_group): the small layers of a DenseNet block fill 64
+// of 256 CUs each when launched alone (their workgroup count is capped by the flush cost per workgroup), a bucket of them
+// fills the chip, and the dependent-node floor (~4.4 us) is paid once per bucket instead of once per layer.
+// The table travels BY VALUE in the kernel arguments (<= 4 KB): a captured step needs no device-side table and no copy node.
+constexpr int kWgfGroupMax = 16;
+struct WgfGroup {
+  int n;
+  int wg0[kWgfGroupMax + 1];                 // first workgroup of layer i (prefix sums of gx[i] * gy[i])
+  int gx[kWgfGroupMax];                      // tile shares of layer i
+  WgfArgs L[kWgfGroupMax];
+};
+static_assert(sizeof(WgfGroup) <= 4096, "kernel argument block");
+
+template <int TH, int TW, int MAXT, int MB, bool DMAX, int CIT = 4>
+__global__ __launch_bounds__(512) void wgrad_fast_group_kernel(const WgfGroup g) {
+  const int b = (int)blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && b >= g.wg0[i + 1]) ++i;          // scalar walk over <= 16 entries
+  const int local = b - g.wg0[i];
+  const int gx = g.gx[i];
+  const int by = local / gx;
+  wgrad_fast_body<TH, TW, MAXT, MB, DMAX, CIT>(g.L[i], local - by * gx, gx, by);
+}
+
+// What launching one layer needs, decided on the host; `group` != nullptr marks a plan that may join a grouped launch.
+struct WgfPlan {
+  const void* single; const void* group;     // the two kernels of the instantiation
+  size_t lds;
+  int ntiles, gy, gx, occ;
+  double t_tile_us, flush_us;                // cost model: one tile of one workgroup; one workgroup's closing atomics
+  WgfArgs a;
+};
+
+// Returns 0 and fills `pl` (gx = the stand-alone grid), 1 when the tile does not fit (caller tries a smaller one).
+template <int TH, int TW, int MAXT, int MB, bool DMAX, int CIT = 4>
+int plan_wgf(const WgfArgs& a, WgfPlan& pl) {
   auto kern = wgrad_fast_kernel<TH, TW, MAXT, MB, DMAX, CIT>;
+  auto gkern = wgrad_fast_group_kernel<TH, TW, MAXT, MB, DMAX, CIT>;
   const int IH = (TH - 1) * a.stride + (a.kh - 1) * a.dil + 1, IW = (TW - 1) * (a.qb ? a.qb : a.stride) + (a.kw - 1) * a.dil + 1;
   const int IWp = (IW + 15) & ~15;
   const int hrounds = (IH * IWp + 63) / 64;
@@ -446,7 +491,8 @@ int launch_wgf(const WgfArgs& a, hipStream_t s) {
   if (a.qb && (IWp % 64) && (64 % IWp)) return 1;   // packed rows: a lane must meet the same chunk in every load round
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gkern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: cannot raise dynamic LDS limit");
     attr_set = true;
   }
@@ -473,35 +519,55 @@ int launch_wgf(const WgfArgs& a, hipStream_t s) {
   if (gx > sdhip_cdiv(256 * occ, gy)) gx = sdhip_cdiv(256 * occ, gy);
   if (gx > sdhip_cdiv(ntiles, 2)) gx = sdhip_cdiv(ntiles, 2);     // at least two tiles per workgroup: the pipeline overlaps them
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(512), lds, s, a);
+  pl.single = (const void*)kern; pl.group = (const void*)gkern;
+  pl.lds = lds; pl.ntiles = ntiles; pl.gy = gy; pl.gx = gx; pl.occ = occ;
+  pl.t_tile_us = t_tile_us; pl.flush_us = flush_us; pl.a = a;
+  return 0;
+}
+
+inline int launch_wgf_plan(const WgfPlan& pl, hipStream_t s) {
+  WgfArgs a = pl.a;
+  void* args[] = {&a};
+  if (hipLaunchKernel(pl.single, dim3(pl.gx, pl.gy), dim3(512), args, pl.lds, s) != hipSuccess)
+    SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv2d_wgrad: launch failed: %s", hipGetErrorString(hipGetLastError()));
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }
 
+// out == nullptr: launch now.  out != nullptr: only plan (the grouped entry point collects plans first).
+template <int TH, int TW, int MAXT, int MB, bool DMAX, int CIT = 4>
+int launch_wgf(const WgfArgs& a, hipStream_t s, WgfPlan* out) {
+  WgfPlan pl;
+  const int rc = plan_wgf<TH, TW, MAXT, MB, DMAX, CIT>(a, pl);
+  if (rc != 0) return rc;
+  if (out) { *out = pl; return SDHIP_OK; }
+  return launch_wgf_plan(pl, s);
+}
+
 // tile choice: wide maps 4x32, else 4x16; 1 = nothing fits (caller falls back to the general kernel)
 template <int MAXT, int MB, bool DMAX, int CIT = 4>
-int launch_wgf_tile(const WgfArgs& a, hipStream_t s) {
+int launch_wgf_tile(const WgfArgs& a, hipStream_t s, WgfPlan* out) {
   if (a.Wo >= 24) {
-    const int rc = launch_wgf<4, 32, MAXT, MB, DMAX, CIT>(a, s);
+    const int rc = launch_wgf<4, 32, MAXT, MB, DMAX, CIT>(a, s, out);
     if (rc != 1) return rc;
   }
-  return launch_wgf<4, 16, MAXT, MB, DMAX, CIT>(a, s);
+  return launch_wgf<4, 16, MAXT, MB, DMAX, CIT>(a, s, out);
 }
 
 template <bool DMAX>
-int launch_wgf_taps(const WgfArgs& a, int T, hipStream_t s) {
+int launch_wgf_taps(const WgfArgs& a, int T, hipStream_t s, WgfPlan* out) {
   const bool narrow = a.Cout <= 32;   // 32 output channels per workgroup: the second wave group takes the odd taps instead
-  if (T == 1) return narrow ? launch_wgf_tile<1, 32, DMAX>(a, s) : launch_wgf_tile<1, 64, DMAX>(a, s);
+  if (T == 1) return narrow ? launch_wgf_tile<1, 32, DMAX>(a, s, out) : launch_wgf_tile<1, 64, DMAX>(a, s, out);
   const bool half = a.Cin <= 32 && !sdhip_diag().wgrad_no_half;   // two input-channel tiles instead of four (CIT)
   if (a.tpb <= 9) {
-    if (half) return narrow ? launch_wgf_tile<9, 32, DMAX, 2>(a, s) : launch_wgf_tile<9, 64, DMAX, 2>(a, s);
-    return narrow ? launch_wgf_tile<9, 32, DMAX>(a, s) : launch_wgf_tile<9, 64, DMAX>(a, s);
+    if (half) return narrow ? launch_wgf_tile<9, 32, DMAX, 2>(a, s, out) : launch_wgf_tile<9, 64, DMAX, 2>(a, s, out);
+    return narrow ? launch_wgf_tile<9, 32, DMAX>(a, s, out) : launch_wgf_tile<9, 64, DMAX>(a, s, out);
   }
-  return half ? launch_wgf_tile<25, 32, DMAX, 2>(a, s) : launch_wgf_tile<25, 32, DMAX>(a, s);
+  return half ? launch_wgf_tile<25, 32, DMAX, 2>(a, s, out) : launch_wgf_tile<25, 32, DMAX>(a, s, out);
 }
 
 // chunk-packed 1x1 weight gradient (WgfArgs::qb): 4x16 pixel tiles, up to 4 chunks as taps
 template <bool DMAX>
-int launch_wgf_packed(const WgfArgs& a, hipStream_t s) { return launch_wgf<4, 16, 4, 64, DMAX>(a, s); }
+int launch_wgf_packed(const WgfArgs& a, hipStream_t s, WgfPlan* out) { return launch_wgf<4, 16, 4, 64, DMAX>(a, s, out); }
 
 }  // namespace

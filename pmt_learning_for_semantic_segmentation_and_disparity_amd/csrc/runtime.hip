@@ -2,6 +2,7 @@
 // error channel.  No global mutable state besides the per-thread message, so
 // entry points are re-entrant from autograd's backward threads.
 #include "sdhip_common.h"
+#include <vector>
 
 #define SDHIP_ABI_VERSION 2
 
@@ -82,4 +83,25 @@ extern "C" int sdhip_abort_capture(void* stream) {
   // the caller and every other stream works again.  Only a stream that is still ACTIVELY capturing is an error.
   if (e == hipSuccess && st == hipStreamCaptureStatusActive) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "abort_capture: the stream is still capturing");
   return was_open;
+}
+
+// ---- node inventory of a captured step (tests: "kernel nodes only", node-count budgets) --------------------------------
+// graph: a hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()).  counts[0..3] = kernel, memset, memcpy,
+// every other node type.  Returns the total number of nodes, < 0 on failure.
+extern "C" int sdhip_graph_node_counts(void* graph, int* counts) {
+  SDHIP_CHECK_ARG(graph && counts, "graph_node_counts: null pointer");
+  size_t n = 0;
+  if (hipGraphGetNodes((hipGraph_t)graph, nullptr, &n) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "graph_node_counts: hipGraphGetNodes failed");
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n && hipGraphGetNodes((hipGraph_t)graph, nodes.data(), &n) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "graph_node_counts: hipGraphGetNodes failed");
+  counts[0] = counts[1] = counts[2] = counts[3] = 0;
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType t;
+    if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "graph_node_counts: hipGraphNodeGetType failed");
+    if (t == hipGraphNodeTypeKernel) ++counts[0];
+    else if (t == hipGraphNodeTypeMemset) ++counts[1];
+    else if (t == hipGraphNodeTypeMemcpy) ++counts[2];
+    else ++counts[3];
+  }
+  return (int)n;
 }

@@ -131,10 +131,46 @@ class StepContext:
         self.unpack_key = None   # the descriptor rows the cached device table was built from
         self.unpack_desc = None
         self.seed = None         # device-resident dropout seed of the owning TrainStep (rng_seed_tensor)
+        # Deferred weight gradients: nothing reads a weight gradient before the optimizer, so every layer's launch is queued
+        # (with its operands kept alive) and join() issues them grouped by kernel instantiation — one grid per bucket instead
+        # of ~200 per-layer launches that fill a quarter of the chip each (sdhip_conv2d_wgrad_group)
+        self.defer_wgrad = not _lib.DIAG_NO_WGRAD_GROUP
+        self.wq = []             # [(WgradItem fields...)] of the running step
+        self.wq_keep = []        # operands of the queued launches
+        self.wq_dt = None
+
+    def flush_wgrads(self):
+        """Issue the queued weight-gradient launches (grouped) on the current stream."""
+        if not self.wq:
+            return
+        import ctypes
+        items = (_lib.WgradItem * len(self.wq))()
+        for it, row in zip(items, self.wq):
+            (it.x, it.dy, it.dw_packed, it.dbias, it.in_scale, it.in_shift, it.B, it.H, it.W, it.Cin, it.ldx, it.Ho, it.Wo, it.Cout,
+             it.lddy, it.kh, it.kw, it.stride, it.dil, it.pad_t, it.pad_l, it.D, it.Do, it.kd, it.sd, it.pad_d, it.in_relu, it.groups) = row
+        n, dt = len(self.wq), self.wq_dt
+        self.wq = []
+        try:
+            call("sdhip_conv2d_wgrad_group", ctypes.cast(items, ctypes.c_void_p), n, dt, stream_ptr())
+        finally:
+            self.wq_keep.clear()
+
+    def flush_to_side(self, min_items=12):
+        """Data parallel: the main stream spends most of the backward pass in latency-bound sync-BN exchanges — buckets of
+        queued weight gradients run beside it on the side stream as soon as they are worth a grid."""
+        if self.side is None or len(self.wq) < min_items:
+            return
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)                  # the queued operands were produced on the main stream
+        self.keep.extend(self.wq_keep)               # the caching allocator must not recycle them before join()
+        with torch.cuda.stream(self.side):
+            self.flush_wgrads()
 
     def join(self):
-        """Main stream waits for the side stream (call after backward, before the optimizer), then ONE launch adds every
-        packed weight-gradient accumulator of the step into the flat gradient buffer."""
+        """Call after backward, before the optimizer: the queued weight gradients are launched (grouped), the main stream
+        waits for the side stream, then ONE launch adds every packed weight-gradient accumulator of the step into the flat
+        gradient buffer."""
+        self.flush_wgrads()
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         if self.unpacks:
@@ -150,6 +186,8 @@ class StepContext:
 
     def begin_step(self):
         self.unpacks = []
+        self.wq = []
+        self.wq_keep.clear()
         if self.arena is not None:
             self.offset = 0
             self.arena.zero_()
@@ -546,7 +584,7 @@ def wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale=None, in_shift=None, in_
     flat gradient buffer (StepContext.direct_grads).  With a StepContext side stream the launches go there: nothing
     downstream of a weight gradient runs before the optimizer, so it overlaps the latency-bound data-gradient chain."""
     c = _ctx[0]
-    if c is not None and c.side is not None and c.direct_grads:
+    if c is not None and c.side is not None and c.direct_grads and not c.defer_wgrad:
         main = torch.cuda.current_stream()
         c.side.wait_stream(main)                     # g and x are produced on the main stream
         c.keep.append((xv, g, in_scale, in_shift))   # the caching allocator must not recycle them before join()
@@ -580,9 +618,20 @@ def _wgrad_impl(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu
         elif tb is None:
             dbias.zero_()
         pz = True
-    call("sdhip_conv2d_wgrad", ptr(xv), ptr(g), ptr(acc), ptr(dbias), ptr(in_scale), ptr(in_shift),
-         B, H, W, Cin, ldx, spec.Ho, spec.Wo, Cout, ldg, spec.kh, spec.kw, spec.stride, spec.dil,
-         spec.pad_t, spec.pad_l, *spec.depth(), int(in_relu), groups, int(pz), dt, stream_ptr())
+    c = _ctx[0]
+    if (c is not None and c.defer_wgrad and c.direct_grads and c.arena is not None and tw is not None and pz
+            and (bias is None or tb is not None)):
+        # queued: launched by StepContext.join() in one grid per kernel instantiation; the operands stay alive until then
+        dpt = lambda t: t.data_ptr() if t is not None else None
+        c.wq.append((dpt(xv), dpt(g), dpt(acc), dpt(dbias), dpt(in_scale), dpt(in_shift), B, H, W, Cin, ldx, spec.Ho, spec.Wo, Cout, ldg,
+                     spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l) + tuple(spec.depth()) + (int(in_relu), groups))
+        c.wq_keep.append((xv, g, in_scale, in_shift))
+        c.wq_dt = dt
+        c.flush_to_side()
+    else:
+        call("sdhip_conv2d_wgrad", ptr(xv), ptr(g), ptr(acc), ptr(dbias), ptr(in_scale), ptr(in_shift),
+             B, H, W, Cin, ldx, spec.Ho, spec.Wo, Cout, ldg, spec.kh, spec.kw, spec.stride, spec.dil,
+             spec.pad_t, spec.pad_l, *spec.depth(), int(in_relu), groups, int(pz), dt, stream_ptr())
     # unpack by the WEIGHT's own channel count (the activation may carry zero-padded extra channels: 8-channel images),
     # depth tap by depth tap for 3-D weights
     gw = None

@@ -66,7 +66,7 @@ class TrainStep:
         self.pack_desc = None
         self.steps_done = 0       # optimizer steps actually EXECUTED (eager steps + graph replays; the recording pass of a capture runs nothing)
         self._capture_fault = None   # tests: a callable invoked inside the capture to make it fail
-        self.debug_graph = False     # tests: keep the captured hipGraph inspectable (graph.debug_dump)
+        self.debug_graph = False     # tests: keep the captured hipGraph inspectable (_lib.graph_node_counts)
         # dropout streams differ per rank (the reference's ranks draw from independently seeded generators) and advance
         # once per step on the device, so that graph replays see new masks (ops.rng_seed_tensor)
         # (the tensor belongs to this step's context: creating a second TrainStep does not restart the first one's stream)
@@ -158,9 +158,7 @@ class TrainStep:
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        graph = torch.cuda.CUDAGraph()
-        if self.debug_graph:
-            graph.enable_debug_mode()            # keeps the hipGraph for graph.debug_dump() (node inventory tests)
+        graph = torch.cuda.CUDAGraph(keep_graph=self.debug_graph)    # kept: _lib.graph_node_counts (node inventory tests)
         # data parallel: the RCCL watchdog thread polls events while we capture; thread-local capture errors keep its
         # (legal) calls from invalidating the capture of this thread
         mode = "thread_local" if self.world_size > 1 else "global"
@@ -238,6 +236,8 @@ class TrainStep:
             import sys
             sys.stderr.write("[TrainStep] could not reset the capture state of torch's CUDA generator: %s\n" % str(e).splitlines()[0])
         self.ctx.unpacks = []
+        self.ctx.wq = []
+        self.ctx.wq_keep.clear()
         self.ctx.keep.clear()
         ops.invalidate_packed_weights()
 

@@ -273,9 +273,9 @@ def test_hip_minidsnet_bf16_error_is_bounded_by_the_networks_own_sensitivity(B, 
     The f32 path's OWN response to a 1e-4 relative perturbation of the input images is 1.7 % (seg1), 0.4 % (disp) and 11 %
     (seg2) relative L2 — amplification factors 170 / 40 / 1100 (tests/diag/gpu_r2_diag.py).  bf16 storage perturbs every
     stored activation by <= 2^-9 = 20 x 1e-4; ~150 stored tensors in sequence add up in quadrature (x 12).  The test
-    measures the f32 response r to the 1e-4 perturbation and requires  err_bf16 <= min(1.2, 50 * r)  per head, i.e. bf16
-    behaves like a perturbation of at most ~2 bf16 ulps per tensor (measured: 20-32 x r; a wrong kernel gives O(1) errors on
-    `disp`, whose bound is 0.2).  The DenseNet taps, where amplification is still small, are bounded directly:
+    measures the f32 response r to the 1e-4 perturbation and requires  err_bf16 <= min(0.2, 50 * r)  on the disparity head,
+    i.e. bf16 behaves like a perturbation of at most ~2 bf16 ulps per tensor (measured: 20-32 x r; a wrong kernel gives O(1)
+    errors there); the segmentation heads get a direction check instead of a cap above 1 (see below).  The DenseNet taps, where amplification is still small, are bounded directly:
     0.3 / 1.8 / 3.8 / 9 / 14.5 % measured -> 1 / 4 / 8 / 18 / 25 %.  Loss within 2 %.  (8, 256, 512) is the bench shape."""
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
     from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import synthetic_batch
@@ -295,7 +295,16 @@ def test_hip_minidsnet_bf16_error_is_bounded_by_the_networks_own_sensitivity(B, 
     for i, name in enumerate(("seg1", "disp", "seg2")):
         r = _rel(o32p[i], o32[i])
         e = _rel(o16[i], o32[i])
-        assert e <= min(1.2, 50.0 * r), (name, e, r)
+        if name == "disp":       # the well-conditioned head: a fixed cap far below what a zero output scores (1.0)
+            assert e <= min(0.2, 50.0 * r), (name, e, r)
+            continue
+        # Segmentation heads: 50 * r exceeds 1 at these weights (measured e = 0.33-0.36 / 0.87-0.89), and a relative-L2 cap
+        # above 1 cannot fail — so none is asserted.  What is asserted is what a zero, constant or unrelated output fails:
+        # the bf16 logits still point the f32 way (cosine > 0.3; measured 0.93 / 0.6).  The same kernels are bounded per head
+        # to a few per cent where the network is not chaotic: tests/test_bf16_parity.py (eval mode).
+        a16, a32 = o16[i].float().flatten(), o32[i].float().flatten()
+        cos = float(torch.dot(a16, a32) / (a16.norm() * a32.norm()).clamp_min(1e-20))
+        assert cos > 0.3 and torch.isfinite(a16).all(), (name, cos, e, r)
     l32 = float(train_loss(o32, seg, disp)); l16 = float(train_loss(o16, seg, disp))
     assert abs(l16 - l32) <= 2e-2 * l32, (l16, l32)
 

@@ -42,7 +42,11 @@ def test_oracle_known_answer(oracle_clib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
-@pytest.mark.parametrize("B,C,H,W,patch,dil", CASES + [(2, 352, 32, 64, (1, 17), 1), (2, 256, 16, 32, (1, 17), 1)])
+@pytest.mark.parametrize("B,C,H,W,patch,dil", CASES + [
+    (2, 352, 32, 64, (1, 17), 1), (2, 256, 16, 32, (1, 17), 1),
+    # the tiled MFMA kernels (bf16): the 2-D correlation of dsnet (models/dsnet_t2.py:129-133,221-223) at its bench-shaped
+    # map, ragged maps, a channel count that is not a multiple of the 64-channel chunk, the (1, 21) patch
+    (2, 352, 32, 64, (17, 17), 1), (1, 64, 13, 21, (17, 17), 1), (2, 40, 9, 30, (1, 21), 1), (1, 448, 16, 24, (17, 17), 1)])
 def test_hip_matches_oracle(oracle_clib, B, C, H, W, patch, dil, dtype, tol):
     from pmt_learning_for_semantic_segmentation_and_disparity_amd.nn import SpatialCorrelationSampler
     a = randn_input(1, "a", (B, C, H, W)); b = randn_input(1, "b", (B, C, H, W))

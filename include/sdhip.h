@@ -392,11 +392,15 @@ int sdhip_cost_volume_fwd(const void* left, const void* right, int ld, void* vol
 int sdhip_cost_volume_bwd(const void* gvol, void* gleft, void* gright, int ld, int B, int D, int H, int W, int C,
                           int dtype, void* stream);
 /* pred[b,h,w] = sum_d softmax_d(trilinear_upsample(cost)[b,d,h,w]) * d, cost [B][D4][H4][W4] -> (Dout,H,W),
- * align_corners=False; the (B,Dout,H,W) tensor is never materialised.  bwd: gcost_f32 is a [B*D4*H4*W4] f32 scratch. */
-int sdhip_softargmin_fwd(const void* cost, void* pred, int B, int D4, int H4, int W4, int Dout, int H, int W,
+ * align_corners=False (models_psmnet/stackhourglass.py:138-155, submodule.py:56-64); the (B,Dout,H,W) tensor is never
+ * materialised.  stats (optional, only with Dout = 4 * D4): f32 [B*H*W][2] = (log-sum-exp, pred) per pixel, which spares the
+ * backward pass the two softmax passes.  bwd: workspace of sdhip_softargmin_bwd_workspace_floats() floats; with
+ * Dout = 4 * D4 it holds the per-pixel gradients of the D4 levels ([B][D4][H][W]), gathered into gcost without atomics. */
+int sdhip_softargmin_fwd(const void* cost, void* pred, float* stats, int B, int D4, int H4, int W4, int Dout, int H, int W,
                          int dtype, void* stream);
-int sdhip_softargmin_bwd(const void* cost, const void* gpred, void* gcost, float* gcost_f32, int B, int D4, int H4, int W4,
-                         int Dout, int H, int W, int dtype, void* stream);
+long sdhip_softargmin_bwd_workspace_floats(int B, int D4, int H4, int W4, int Dout, int H, int W);
+int sdhip_softargmin_bwd(const void* cost, const void* gpred, const float* stats, void* gcost, float* workspace,
+                         long workspace_floats, int B, int D4, int H4, int W4, int Dout, int H, int W, int dtype, void* stream);
 /* y = log_softmax(x) over the channel axis (F.log_softmax(.., dim=1), models/dsnet_t2.py:216,270) and its backward
  * gx = gy - exp(y) * sum_c gy. */
 int sdhip_log_softmax_fwd(const void* x, int ldx, void* y, int ldy, long npix, int C, int dtype, void* stream);

@@ -75,8 +75,8 @@ SIGNATURES = {
     "sdhip_stuff": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_cost_volume_fwd": [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_cost_volume_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
-    "sdhip_softargmin_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    "sdhip_softargmin_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_softargmin_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sdhip_softargmin_bwd": [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_log_softmax_fwd": [_p, _i, _p, _i, _l, _i, _i, _p],
     "sdhip_log_softmax_bwd": [_p, _i, _p, _i, _p, _i, _l, _i, _i, _p],
     "sdhip_l1_loss": [_p, _p, _p, _p, _l, _f, _i, _i, _p],
@@ -97,6 +97,8 @@ _lib.sdhip_lovasz_workspace_bytes.argtypes = [_l, _i]
 _lib.sdhip_lovasz_workspace_bytes.restype = _l
 _lib.sdhip_flip_sample_workspace_bytes.argtypes = [_i, _i, _i]
 _lib.sdhip_flip_sample_workspace_bytes.restype = _l
+_lib.sdhip_softargmin_bwd_workspace_floats.argtypes = [_i] * 7
+_lib.sdhip_softargmin_bwd_workspace_floats.restype = _l
 _lib.sdhip_conv_packed_elems.argtypes = [_i, _i, _i, _i]
 _lib.sdhip_conv_packed_elems.restype = _l
 for _name, _args in SIGNATURES.items():

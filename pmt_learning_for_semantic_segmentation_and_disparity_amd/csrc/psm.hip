@@ -257,6 +257,178 @@ __global__ __launch_bounds__(256) void softargmin_bwd(const T* __restrict__ cost
   }
 }
 
+// ---------------------------------------------------------------- soft-argmin, x4 form (Dout = 4 * D4: PSMNet's 1/4-scale volume)
+// With an exact factor 4 the align_corners=False depth interpolation has four fixed weight pairs: for d = 4k + r
+//   v(4k)   = c[k] + 0.375 (c[k-1] - c[k]),  v(4k+1) = c[k] + 0.125 (c[k-1] - c[k]),
+//   v(4k+2) = c[k] + 0.125 (c[k+1] - c[k]),  v(4k+3) = c[k] + 0.375 (c[k+1] - c[k]),      c[-1] := c[0], c[D4] := c[D4-1]
+// (ATen's area_pixel source index (d + 0.5) / 4 - 0.5, clamped at 0), so the 192-level loops need no index arithmetic and
+// no branches: one pass for the maximum, one for the two sums.  The general kernels above spend most of their time in
+// lin_src() and the branchy online softmax (238 us forward, 1.34 ms backward per head at B = 8, 256 x 512).
+template <typename T>
+__device__ __forceinline__ void sa_column(const T* __restrict__ cost, float (*cs)[256], long b, int D4, int H4, int W4,
+                                          const Lin& lh, const Lin& lw) {
+  const float w00 = (1.f - lh.l1) * (1.f - lw.l1), w01 = (1.f - lh.l1) * lw.l1, w10 = lh.l1 * (1.f - lw.l1), w11 = lh.l1 * lw.l1;
+  const int o00 = lh.i0 * W4 + lw.i0, o01 = lh.i0 * W4 + lw.i1, o10 = lh.i1 * W4 + lw.i0, o11 = lh.i1 * W4 + lw.i1;
+  const T* c = cost + (b * D4) * (long)H4 * W4;
+  const int plane = H4 * W4;
+#pragma unroll 4
+  for (int d4 = 0; d4 < D4; ++d4, c += plane)
+    cs[d4][threadIdx.x] = w00 * Elem<T>::ld(c + o00) + w01 * Elem<T>::ld(c + o01) + w10 * Elem<T>::ld(c + o10) + w11 * Elem<T>::ld(c + o11);
+}
+
+// (log-sum-exp, expectation) of the 4 * D4 interpolated levels of the lane's column cs[.][tid]
+__device__ __forceinline__ void sa_reduce4(float (*cs)[256], int D4, float& lse, float& pred) {
+  const int t = threadIdx.x;
+  float m = -INFINITY;
+  {
+    float cm = cs[0][t], c0 = cm;
+    for (int k = 0; k < D4; ++k) {
+      const float cp = cs[k + 1 < D4 ? k + 1 : k][t];
+      const float dm = cm - c0, dp = cp - c0;
+      m = fmaxf(m, fmaxf(fmaxf(fmaf(0.375f, dm, c0), fmaf(0.125f, dm, c0)), fmaxf(fmaf(0.125f, dp, c0), fmaf(0.375f, dp, c0))));
+      cm = c0; c0 = cp;
+    }
+  }
+  float s = 0.f, e = 0.f;
+  {
+    float cm = cs[0][t], c0 = cm;
+    for (int k = 0; k < D4; ++k) {
+      const float cp = cs[k + 1 < D4 ? k + 1 : k][t];
+      const float dm = cm - c0, dp = cp - c0, base = c0 - m;
+      const float x0 = __expf(fmaf(0.375f, dm, base)), x1 = __expf(fmaf(0.125f, dm, base));
+      const float x2 = __expf(fmaf(0.125f, dp, base)), x3 = __expf(fmaf(0.375f, dp, base));
+      const float d0 = (float)(4 * k);
+      s += (x0 + x1) + (x2 + x3);
+      e += fmaf(x0, d0, x1 * (d0 + 1.f)) + fmaf(x2, d0 + 2.f, x3 * (d0 + 3.f));
+      cm = c0; c0 = cp;
+    }
+  }
+  lse = m + __logf(s);
+  pred = e / s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softargmin4_fwd(const T* __restrict__ cost, T* __restrict__ pred, float* __restrict__ stats,
+                                                       int B, int D4, int H4, int W4, int H, int W) {
+  __shared__ float cs[kMaxD4][256];
+  const float shh = (float)H4 / (float)H, sw = (float)W4 / (float)W;
+  const long npix = (long)B * H * W;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < npix;
+  const int w = live ? (int)(p % W) : 0;
+  const int h = live ? (int)((p / W) % H) : 0;
+  const long b = live ? p / ((long)W * H) : 0;
+  sa_column<T>(cost, cs, b, D4, H4, W4, lin_src(h, shh, H4), lin_src(w, sw, W4));
+  float lse, pv;
+  sa_reduce4(cs, D4, lse, pv);
+  if (live) {
+    Elem<T>::st(pred + p, pv);
+    if (stats) { stats[2 * p] = lse; stats[2 * p + 1] = pv; }
+  }
+}
+
+// Backward, stage 1: per full-resolution pixel, the gradient folded back onto the D4 low-resolution LEVELS of its own column,
+//   t[b, k, h, w] = sum_d Wd[d, k] * g * p_d * (d - pred),
+// written [B][D4][H][W] in the activations' own type (lanes along w: coalesced; bf16 halves the 200 MB this intermediate
+// takes at B = 8 — its 64 contributions per cell are summed in f32 by stage 2, and the result is rounded to bf16 anyway).
+// Stage 2 gathers it through the adjoint of the bilinear map.
+template <typename T>
+__global__ __launch_bounds__(256) void softargmin4_bwd_levels(const T* __restrict__ cost, const T* __restrict__ g,
+                                                              const float* __restrict__ stats, T* __restrict__ tl,
+                                                              int B, int D4, int H4, int W4, int H, int W) {
+  __shared__ float cs[kMaxD4][256];
+  const float shh = (float)H4 / (float)H, sw = (float)W4 / (float)W;
+  const long npix = (long)B * H * W;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < npix;
+  const int w = live ? (int)(p % W) : 0;
+  const int h = live ? (int)((p / W) % H) : 0;
+  const long b = live ? p / ((long)W * H) : 0;
+  sa_column<T>(cost, cs, b, D4, H4, W4, lin_src(h, shh, H4), lin_src(w, sw, W4));
+  float lse, pv;
+  if (stats) { lse = stats[2 * (live ? p : 0)]; pv = stats[2 * (live ? p : 0) + 1]; }
+  else sa_reduce4(cs, D4, lse, pv);
+  const float gv = live ? Elem<T>::ld(g + p) : 0.f;
+  const int t = threadIdx.x;
+  T* dst = tl + ((b * D4) * H + h) * (long)W + w;
+  const long plane = (long)H * W;
+  float cm = cs[0][t], c0 = cm;
+  float tm = 0.f, t0 = 0.f;      // gradients of levels k - 1 and k gathered so far
+  for (int k = 0; k < D4; ++k) {
+    const float cp = cs[k + 1 < D4 ? k + 1 : k][t];
+    const float dm = cm - c0, dp = cp - c0, base = c0 - lse;
+    const float d0 = (float)(4 * k) - pv;
+    const float g0 = gv * __expf(fmaf(0.375f, dm, base)) * d0, g1 = gv * __expf(fmaf(0.125f, dm, base)) * (d0 + 1.f);
+    const float g2 = gv * __expf(fmaf(0.125f, dp, base)) * (d0 + 2.f), g3 = gv * __expf(fmaf(0.375f, dp, base)) * (d0 + 3.f);
+    const float lo = fmaf(0.375f, g0, 0.125f * g1), hi = fmaf(0.125f, g2, 0.375f * g3);
+    float mid = fmaf(0.625f, g0 + g3, 0.875f * (g1 + g2));
+    float tp = hi;
+    if (k == 0) mid += lo; else tm += lo;                       // c[-1] is c[0]
+    if (k == D4 - 1) { mid += hi; tp = 0.f; }                   // c[D4] is c[D4-1]
+    t0 += mid;
+    if (k > 0 && live) Elem<T>::st(dst + (long)(k - 1) * plane, tm);   // level k - 1 is complete
+    tm = t0; t0 = tp;
+    cm = c0; c0 = cp;
+  }
+  if (live) Elem<T>::st(dst + (long)(D4 - 1) * plane, tm);
+}
+
+// Backward, stage 2: gcost[b, k, h4, w4] = sum over the pixels (h, w) whose bilinear footprint contains (h4, w4) of
+// Wh[h, h4] * Ww[w, w4] * t[b, k, h, w] — one lane per low-resolution cell, no atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void softargmin_bwd_cells(const T* __restrict__ tl, T* __restrict__ gcost,
+                                                            int B, int D4, int H4, int W4, int H, int W) {
+  const float shh = (float)H4 / (float)H, sw = (float)W4 / (float)W;
+  // a workgroup = 8 x 32 cells of one (b, k) plane: neighbouring cells share half of their footprints, which then meet in
+  // the workgroup's L1 instead of being fetched again by a workgroup far away in time
+  const int tw = (W4 + 31) >> 5, th = (H4 + 7) >> 3;
+  int t = blockIdx.x;
+  const int tx = t % tw; t /= tw;
+  const int ty = t % th;
+  const long bk = t / th;                                        // b * D4 + k
+  const int w4 = tx * 32 + (threadIdx.x & 31), h4 = ty * 8 + (threadIdx.x >> 5);
+  if (w4 >= W4 || h4 >= H4) return;
+  const long i = (bk * H4 + h4) * (long)W4 + w4;
+  // pixels whose source coordinate lies within one cell of (h4, w4); the exact weights below are zero for the rest
+  const int hlo = max(0, (int)floorf(((float)h4 - 0.5f) / shh - 0.5f)), hhi = min(H - 1, (int)ceilf(((float)h4 + 1.5f) / shh - 0.5f));
+  const int wlo = max(0, (int)floorf(((float)w4 - 0.5f) / sw - 0.5f)), whi = min(W - 1, (int)ceilf(((float)w4 + 1.5f) / sw - 0.5f));
+  const T* src = tl + bk * (long)H * W;
+  float acc = 0.f;
+  constexpr int NC = 12;                                         // candidates per axis held in registers (x4 scale: 10)
+  auto weight = [](int pix, float scale, int in, int cell) {
+    const Lin l = lin_src(pix, scale, in);
+    return (l.i0 == cell ? 1.f - l.l1 : 0.f) + (l.i1 == cell ? l.l1 : 0.f);
+  };
+  if (hhi - hlo < NC && whi - wlo < NC) {
+    // the column weights are the same for every row: computed once (the weight search was most of this kernel's time)
+    float ww[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) ww[j] = wlo + j <= whi ? weight(wlo + j, sw, W4, w4) : 0.f;
+#pragma unroll
+    for (int r = 0; r < NC; ++r) {
+      const int h = hlo + r;
+      const float wh = h <= hhi ? weight(h, shh, H4, h4) : 0.f;
+      if (wh != 0.f) {
+        const T* row = src + (long)h * W + wlo;
+        float rs = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+          if (ww[j] != 0.f) rs = fmaf(ww[j], Elem<T>::ld(row + j), rs);
+        acc = fmaf(wh, rs, acc);
+      }
+    }
+  } else {
+    for (int h = hlo; h <= hhi; ++h) {
+      const float wh = weight(h, shh, H4, h4);
+      if (wh == 0.f) continue;
+      float row = 0.f;
+      for (int w = wlo; w <= whi; ++w) row = fmaf(weight(w, sw, W4, w4), Elem<T>::ld(src + (long)h * W + w), row);
+      acc = fmaf(wh, row, acc);
+    }
+  }
+  Elem<T>::st(gcost + i, acc);
+}
+
 template <typename T>
 __global__ void f32_to_T_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) Elem<T>::st(dst + i, src[i]);
@@ -322,25 +494,56 @@ extern "C" int sdhip_cost_volume_bwd(const void* gvol, void* gleft, void* gright
   return SDHIP_OK;
 }
 
-extern "C" int sdhip_softargmin_fwd(const void* cost, void* pred, int B, int D4, int H4, int W4, int Dout, int H, int W,
+extern "C" int sdhip_softargmin_fwd(const void* cost, void* pred, float* stats, int B, int D4, int H4, int W4, int Dout, int H, int W,
                                     int dtype, void* stream) {
   SDHIP_CHECK_ARG(cost && pred && B > 0 && D4 > 0 && D4 <= kMaxD4 && H4 > 0 && W4 > 0 && Dout > 0 && H > 0 && W > 0,
                   "softargmin_fwd: bad arguments (at most %d low-resolution disparity levels)", kMaxD4);
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "softargmin_fwd: unknown dtype %d", dtype);
   const long np = (long)B * H * W;
-  if (dtype == SDHIP_F32) hipLaunchKernelGGL(softargmin_fwd<float>, grid_for(np), dim3(256), 0, (hipStream_t)stream, (const float*)cost, (float*)pred, B, D4, H4, W4, Dout, H, W);
-  else hipLaunchKernelGGL(softargmin_fwd<bf16_t>, grid_for(np), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)cost, (bf16_t*)pred, B, D4, H4, W4, Dout, H, W);
+  hipStream_t st = (hipStream_t)stream;
+  if (Dout == 4 * D4) {
+    const dim3 grid((unsigned)((np + 255) / 256));
+    if (dtype == SDHIP_F32) hipLaunchKernelGGL(softargmin4_fwd<float>, grid, dim3(256), 0, st, (const float*)cost, (float*)pred, stats, B, D4, H4, W4, H, W);
+    else hipLaunchKernelGGL(softargmin4_fwd<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)cost, (bf16_t*)pred, stats, B, D4, H4, W4, H, W);
+    SDHIP_LAUNCH_CHECK();
+    return SDHIP_OK;
+  }
+  SDHIP_CHECK_ARG(!stats, "softargmin_fwd: per-pixel statistics are produced for Dout = 4 * D4 only");
+  if (dtype == SDHIP_F32) hipLaunchKernelGGL(softargmin_fwd<float>, grid_for(np), dim3(256), 0, st, (const float*)cost, (float*)pred, B, D4, H4, W4, Dout, H, W);
+  else hipLaunchKernelGGL(softargmin_fwd<bf16_t>, grid_for(np), dim3(256), 0, st, (const bf16_t*)cost, (bf16_t*)pred, B, D4, H4, W4, Dout, H, W);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }
 
-extern "C" int sdhip_softargmin_bwd(const void* cost, const void* gpred, void* gcost, float* gcost_f32, int B, int D4, int H4, int W4,
-                                    int Dout, int H, int W, int dtype, void* stream) {
-  SDHIP_CHECK_ARG(cost && gpred && gcost && gcost_f32 && B > 0 && D4 > 0 && D4 <= kMaxD4 && H4 > 0 && W4 > 0 && Dout > 0 && H > 0 && W > 0,
+extern "C" long sdhip_softargmin_bwd_workspace_floats(int B, int D4, int H4, int W4, int Dout, int H, int W) {
+  const long levels = (long)B * D4 * H * W, cells = (long)B * D4 * H4 * W4;
+  return Dout == 4 * D4 ? levels : cells;
+}
+
+extern "C" int sdhip_softargmin_bwd(const void* cost, const void* gpred, const float* stats, void* gcost, float* workspace,
+                                    long workspace_floats, int B, int D4, int H4, int W4, int Dout, int H, int W, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(cost && gpred && gcost && workspace && B > 0 && D4 > 0 && D4 <= kMaxD4 && H4 > 0 && W4 > 0 && Dout > 0 && H > 0 && W > 0,
                   "softargmin_bwd: bad arguments");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "softargmin_bwd: unknown dtype %d", dtype);
+  SDHIP_CHECK_ARG(workspace_floats >= sdhip_softargmin_bwd_workspace_floats(B, D4, H4, W4, Dout, H, W),
+                  "softargmin_bwd: workspace too small (%ld floats)", workspace_floats);
   hipStream_t st = (hipStream_t)stream;
   const long nv = (long)B * D4 * H4 * W4, np = (long)B * H * W;
+  if (Dout == 4 * D4) {
+    // two stages, no atomics: per-pixel gradients of the D4 levels (f32, [B][D4][H][W]), then the bilinear adjoint per cell
+    const dim3 g1((unsigned)((np + 255) / 256)), g2((unsigned)((long)B * D4 * sdhip_cdiv(H4, 8) * sdhip_cdiv(W4, 32)));
+    (void)nv;
+    if (dtype == SDHIP_F32) {
+      hipLaunchKernelGGL(softargmin4_bwd_levels<float>, g1, dim3(256), 0, st, (const float*)cost, (const float*)gpred, stats, workspace, B, D4, H4, W4, H, W);
+      hipLaunchKernelGGL(softargmin_bwd_cells<float>, g2, dim3(256), 0, st, (const float*)workspace, (float*)gcost, B, D4, H4, W4, H, W);
+    } else {
+      hipLaunchKernelGGL(softargmin4_bwd_levels<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)cost, (const bf16_t*)gpred, stats, (bf16_t*)workspace, B, D4, H4, W4, H, W);
+      hipLaunchKernelGGL(softargmin_bwd_cells<bf16_t>, g2, dim3(256), 0, st, (const bf16_t*)workspace, (bf16_t*)gcost, B, D4, H4, W4, H, W);
+    }
+    SDHIP_LAUNCH_CHECK();
+    return SDHIP_OK;
+  }
+  float* gcost_f32 = workspace;
   if (sdhip_zero_async(gcost_f32, nv * sizeof(float), st) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "softargmin_bwd: memset failed");
   const size_t sa_lds = ((size_t)kMaxD4 * 256 + (size_t)kMaxD4 * kSaCells) * sizeof(float);
   static bool sa_attr = false;
@@ -352,7 +555,6 @@ extern "C" int sdhip_softargmin_bwd(const void* cost, const void* gpred, void* g
   }
   const long sa_tiles = (long)B * sdhip_cdiv(H, kSaTH) * sdhip_cdiv(W, kSaTW);
   const int sa_grid = (int)(sa_tiles < 2048 ? sa_tiles : 2048);
-  (void)np;
   if (dtype == SDHIP_F32) {
     hipLaunchKernelGGL(softargmin_bwd<float>, dim3(sa_grid), dim3(256), sa_lds, st, (const float*)cost, (const float*)gpred, gcost_f32, B, D4, H4, W4, Dout, H, W);
     hipLaunchKernelGGL(f32_to_T_kernel<float>, grid_for(nv), dim3(256), 0, st, gcost_f32, (float*)gcost, nv);

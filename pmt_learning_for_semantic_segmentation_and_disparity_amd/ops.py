@@ -1663,18 +1663,21 @@ class _SoftArgminFn(torch.autograd.Function):
         B = Bimg // D4
         c = cost.contiguous()
         pred = torch.empty((B, H, W), dtype=cost.dtype, device=cost.device)
-        call("sdhip_softargmin_fwd", ptr(c), ptr(pred), B, D4, H4, W4, maxdisp, H, W, dtype_code(cost), stream_ptr())
-        ctx.save_for_backward(c)
+        # (log-sum-exp, pred) per pixel: the backward pass starts from them instead of repeating the two softmax passes
+        stats = torch.empty((B * H * W, 2), dtype=torch.float32, device=cost.device) if (maxdisp == 4 * D4 and ctx.needs_input_grad[0]) else None
+        call("sdhip_softargmin_fwd", ptr(c), ptr(pred), ptr(stats), B, D4, H4, W4, maxdisp, H, W, dtype_code(cost), stream_ptr())
+        ctx.save_for_backward(c, stats)
         ctx.cfg = (B, D4, H4, W4, maxdisp, H, W)
         return pred
 
     @staticmethod
     def backward(ctx, g):
-        (c,) = ctx.saved_tensors
+        c, stats = ctx.saved_tensors
         B, D4, H4, W4, maxdisp, H, W = ctx.cfg
         gc = torch.empty_like(c)
-        tmp = torch.empty(c.numel(), dtype=torch.float32, device=c.device)
-        call("sdhip_softargmin_bwd", ptr(c), ptr(g.contiguous()), ptr(gc), ptr(tmp), B, D4, H4, W4, maxdisp, H, W,
+        nws = _lib._lib.sdhip_softargmin_bwd_workspace_floats(B, D4, H4, W4, maxdisp, H, W)
+        tmp = torch.empty(nws, dtype=torch.float32, device=c.device)
+        call("sdhip_softargmin_bwd", ptr(c), ptr(g.contiguous()), ptr(stats), ptr(gc), ptr(tmp), nws, B, D4, H4, W4, maxdisp, H, W,
              dtype_code(c), stream_ptr())
         return gc, None, None, None, None
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_signatures_cover_the_header():
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import _lib
-    bound = set(_lib.SIGNATURES) | {"sdhip_abi_version", "sdhip_last_error", "sdhip_conv_packed_elems", "sdhip_lovasz_workspace_bytes", "sdhip_diag_reload", "sdhip_abort_capture", "sdhip_flip_sample_workspace_bytes", "sdhip_graph_node_counts"}
+    bound = set(_lib.SIGNATURES) | {"sdhip_abi_version", "sdhip_last_error", "sdhip_conv_packed_elems", "sdhip_lovasz_workspace_bytes", "sdhip_diag_reload", "sdhip_abort_capture", "sdhip_flip_sample_workspace_bytes", "sdhip_graph_node_counts", "sdhip_softargmin_bwd_workspace_floats"}
     assert set(_declared()) == bound, set(_declared()) ^ bound
 
 

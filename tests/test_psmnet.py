@@ -128,6 +128,26 @@ def test_hip_cost_volume_and_softargmin_match_torch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D4,maxd,H4,W4,H,W", [(6, 24, 8, 8, 24, 20), (5, 17, 8, 8, 24, 20), (16, 64, 9, 7, 36, 28), (3, 12, 5, 6, 20, 24)])
+def test_hip_softargmin_scales(D4, maxd, H4, W4, H, W):
+    """Soft-argmin at other scale factors than PSMNet's exact x4: depth x4 with non-integer spatial factors (the gather
+    backward's footprint search), a depth factor that is not 4 (general kernels), ragged sizes — forward and the gradient
+    w.r.t. the low-resolution cost against the unfused ATen sequence (stackhourglass.py:138-155, submodule.py:56-64)."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    B = 2
+    c = (randn_input(61, "cs", (B, 1, D4, H4, W4)) * 2.0).requires_grad_(True)
+    up = F.interpolate(c, [maxd, H, W], mode='trilinear').squeeze(1)
+    pred = torch.sum(F.softmax(up, 1) * torch.arange(maxd, dtype=torch.float32).view(1, -1, 1, 1), 1)
+    gp = randn_input(62, "gps", tuple(pred.shape))
+    pred.backward(gp)
+    cd = _vol_to_images(c.detach().cuda()).requires_grad_(True)
+    pd = ops.soft_argmin(cd, D4, maxd, H, W)
+    pd.backward(gp.cuda())
+    assert float((pd.cpu() - pred.detach()).abs().max()) < 1e-4 * maxd
+    assert _rel(_images_to_vol(cd.grad, B).cpu(), c.grad) < 1e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_hip_softargmin_maxdisp192(dtype):
     """The 192-level head of BASELINE configs 3-4 (models_psmnet/stackhourglass.py:138-155 with maxdisp = 192): cost

@@ -83,15 +83,27 @@ def test_single_rank_is_a_noop():
 # ------------------------------------------------------------------ GPU: the real kernels under world_size 2
 # Both ranks share the one GPU of the test box; the collectives go over gloo (RCCL refuses two ranks per device).
 def _spawn2(target, port):
+    import queue
+    import time
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=target, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r[0])
+    res, t0 = [], time.time()
+    while len(res) < len(procs):
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > 400:      # a rank that raised never reports: fail NOW, not after the queue timeout
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise RuntimeError("rank process died (exit codes %s) or timed out; its traceback is on stderr" % dead)
     for p in procs:
         p.join(60)
-    return res
+    return sorted(res, key=lambda r: r[0])
 
 
 def _block_model_and_data():
@@ -188,6 +200,58 @@ def test_gpu_two_ranks_match_one_rank_on_the_joint_batch():
         bn = m.resnet_features.resnet_features.norm5
         np.testing.assert_allclose(r[3], bn.running_mean.cpu().numpy(), rtol=1e-3, atol=1e-5)
         np.testing.assert_allclose(r[4], bn.running_var.cpu().numpy(), rtol=1e-3, atol=1e-5)
+    assert np.array_equal(res[0][2], res[1][2])      # both ranks hold the same reduced gradient
+
+
+def _psm_rank_worker(rank, world, port, q):
+    """One data-parallel rank of a PSMNet(64) training step: 2-D towers (BatchNorm2d), cost volume, 3-D hourglasses
+    (BatchNorm3d incl. the sub-pixel transposed convolutions), soft-argmin heads; mean-L1 loss of the three predictions."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from oracle.detweights import fill_state_dict
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.psmnet import PSMNet
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    m = fill_state_dict(PSMNet(64), 45).cuda().train()
+    step = TrainStep(m, dtype=torch.float32, use_graph=False, world_size=world, process_group=dist.group.WORLD,
+                     loss_fn=lambda outs, seg, disp: ops.mean_l1_loss(outs, disp[:, 0]))
+    full = synthetic_batch(2, 256, 256, seed=79)
+    shard = [t[rank:rank + 1].contiguous() for t in full]
+    loss = step.forward_backward(*shard)
+    step.all_reduce()
+    torch.cuda.synchronize()
+    rm = [b.running_mean.cpu().numpy() for b in m.modules() if isinstance(b, torch.nn.BatchNorm3d)][:3]
+    q.put((rank, float(loss), (step.flat_g / world).cpu().numpy(), rm))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_gpu_psmnet_two_ranks_match_one_rank_on_the_joint_batch():
+    """BASELINE config 4's network family under data parallelism: PSMNet(64), 2 ranks x 1 pair (256 x 256: the SPP branch pools 64 x 64 windows of the 1/4-scale map) with the sync-BN
+    exchange on every BatchNorm2d / BatchNorm3d (torch_implementation.py:739-741) vs 1 rank x 2 pairs: loss mean 1e-4, running
+    statistics 1e-3, the reduced gradient identical on both ranks and within 2 % relative L2 of the single-rank one."""
+    import numpy as np
+    res = _spawn2(_psm_rank_worker, 29500 + (os.getpid() % 400))
+    from oracle.detweights import fill_state_dict
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops, parallel
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.psmnet import PSMNet
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    parallel.configure(None, 1)
+    m = fill_state_dict(PSMNet(64), 45).cuda().train()
+    step = TrainStep(m, dtype=torch.float32, use_graph=False, loss_fn=lambda outs, seg, disp: ops.mean_l1_loss(outs, disp[:, 0]))
+    loss = step.forward_backward(*synthetic_batch(2, 256, 256, seed=79))
+    torch.cuda.synchronize()
+    ops.set_step_context(None)
+    g1 = step.flat_g.cpu().numpy()
+    assert abs(0.5 * (res[0][1] + res[1][1]) - float(loss)) < 1e-4 * max(1.0, abs(float(loss)))
+    rm1 = [b.running_mean.cpu().numpy() for b in m.modules() if isinstance(b, torch.nn.BatchNorm3d)][:3]
+    for r in res:
+        rel = np.linalg.norm(r[2] - g1) / max(1e-12, np.linalg.norm(g1))
+        assert rel < 2e-2, "gradient mismatch, relative L2 %.3e" % rel
+        for a, b in zip(r[3], rm1):
+            np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5)
     assert np.array_equal(res[0][2], res[1][2])      # both ranks hold the same reduced gradient
 
 

@@ -228,3 +228,34 @@ def test_hip_psmnet_matches_golden(mode):
         if key in gold.files and mode == "train":
             w = float(gold[key])
             assert abs(np.sqrt(v) - w) <= 3e-2 * max(w, 1e-6), (key, np.sqrt(v), w)
+
+
+@pytest.mark.gpu
+def test_hip_psmnet192_config4_properties():
+    """BASELINE config 4 at its stated workload: PSMNet(192) (util/utilLoadNetwork.py:52-54), 960 x 512 (W x H), batch 4 per
+    GPU, bf16, the captured training step (cost volume (4,64,48,128,240): models_psmnet/stackhourglass.py:110-119).  Shapes,
+    finite predictions in the disparity range, finite gradients for every parameter, a loss that falls over optimizer steps
+    on one batch and replays that are reproducible at lr 0."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.psmnet import PSMNet
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    B, H, W = 4, 512, 960
+    torch.manual_seed(0)
+    m = PSMNet(192).cuda().train()
+    left, right, seg, disp = synthetic_batch(B, H, W, seed=9)
+    disp = disp * 10.0                                   # spread the targets over the disparity range
+    with torch.no_grad():
+        outs = m(left.bfloat16(), right.bfloat16())
+    assert len(outs) == 3
+    for o in outs:
+        assert tuple(o.shape) == (B, H, W) and torch.isfinite(o.float()).all()
+        assert float(o.float().min()) >= 0.0 and float(o.float().max()) <= 191.0 + 1.0       # an expectation over 0..191 (bf16 rounding)
+    loss_fn = lambda outs, seg, disp: ops.mean_l1_loss(outs, disp[:, 0])
+    ts = TrainStep(m, dtype=torch.bfloat16, use_graph=True, lr=1e-3, loss_fn=loss_fn)
+    losses = [float(ts(left, right, seg, disp)) for _ in range(6)]
+    assert ts.graph is not None and all(np.isfinite(losses)), losses
+    assert torch.isfinite(ts.flat_g).all() and float(ts.flat_g.norm()) > 0
+    assert min(losses[3:]) < losses[0], losses
+    ops.set_step_context(None)
+    del ts, m
+    torch.cuda.empty_cache()

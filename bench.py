@@ -149,7 +149,7 @@ def hbm_kernel_roofline(dtype, B, H, W):
     with torch.cuda.stream(s):
         def launch():
             call("sdhip_bn_bwd_apply_fin", ptr(g), C, ptr(x), C, ptr(gx), C, ptr(scale), ptr(shift), ptr(dsc), ptr(dsh), ops.NREP,
-                 ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), 0, npix, C, 1, float(npix), 1, dt,
+                 ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), 0, 1.0, npix, C, 1, float(npix), 1, dt,
                  ctypes_stream(s))
         for _ in range(3):
             launch()

@@ -262,7 +262,7 @@ int sdhip_bn_finalize_bwd(const float* dscale, const float* dshift, int nrep, co
 int sdhip_stats_fix_fin(const void* gin, int ldgi, const void* x, int ldx, void* gout, int ldgo, long npix,
                         double* dS, int ldc, int cs, const float* dscale, const float* dshift, int nrep,
                         const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                        int accumulate_params, int Cf, int groups, double count, int dtype, void* stream);
+                        int accumulate_params, float param_scale, int Cf, int groups, double count, int dtype, void* stream);
 /* y = act(x*scale[g][c] + shift[g][c]) (+ res). scale/shift may be NULL (identity). */
 int sdhip_affine_act(const void* x, int ldx, void* y, int ldy, const void* res, int ldr,
                      const float* scale, const float* shift, long npix, int C, int groups, int act,
@@ -306,13 +306,13 @@ int sdhip_affine_act_bn(const void* x, int ldx, void* y, int ldy, const void* re
 int sdhip_bn_bwd_apply_fin(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
                            const float* scale, const float* shift, const float* dscale, const float* dshift, int nrep,
                            const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                           int accumulate_params, long npix, int C, int groups, double count, int act, int dtype, void* stream);
+                           int accumulate_params, float param_scale, long npix, int C, int groups, double count, int act, int dtype, void* stream);
 /* bn_bwd_apply_fin with the two reductions supplied as f64 [nrep][groups][2][C] = (sum(gm*x), sum(gm)) — the layout in
  * which the epilogue of sdhip_conv2d_fwd_bnbwd adds them. */
 int sdhip_bn_bwd_apply_fin_d(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
                              const float* scale, const float* shift, const double* sums, int nrep,
                              const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                             int accumulate_params, long npix, int C, int groups, double count, int act, int dtype, void* stream);
+                             int accumulate_params, float param_scale, long npix, int C, int groups, double count, int act, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Pooling / resizing / broadcast product on NHWC tensors (HBM bound).

@@ -56,7 +56,7 @@ SIGNATURES = {
     "sdhip_stats_replica_sum": [_p, _p, _i, _i, _i, _i, _i, _p],
     "sdhip_bn_fold_finalize": [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _d, _f, _f, _p],
     "sdhip_bn_finalize": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _d, _f, _f, _p],
-    "sdhip_stats_fix_fin": [_p, _i, _p, _i, _p, _i, _l, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _d, _i, _p],
+    "sdhip_stats_fix_fin": [_p, _i, _p, _i, _p, _i, _l, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _i, _i, _d, _i, _p],
     "sdhip_bn_finalize_bwd": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _i, _p],
     "sdhip_affine_act": [_p, _i, _p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _i, _p],
     "sdhip_affine_act_bwd": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _l, _i, _i, _i, _i, _i, _i, _p],
@@ -87,8 +87,8 @@ SIGNATURES = {
     "sdhip_prepare_sample": [_p, _p, _l, _i, _p, _l, _i, _i, _i, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p, _p,
                              _p, _p, _i, _p, _i, _i, _p, _i, _p],
     "sdhip_flip_sample": [_p, _p, _i, _p, _i, _i, _p, _i, _i, _p, _l, _i, _p],
-    "sdhip_bn_bwd_apply_fin": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _d, _i, _i, _p],
-    "sdhip_bn_bwd_apply_fin_d": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _d, _i, _i, _p],
+    "sdhip_bn_bwd_apply_fin": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _l, _i, _i, _d, _i, _i, _p],
+    "sdhip_bn_bwd_apply_fin_d": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _l, _i, _i, _d, _i, _i, _p],
     "sdhip_conv2d_fwd_bnpro": [_p, _p, _p, _p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _d, _f, _f] + [_i] * 15 + [_p],
     "sdhip_conv2d_fwd_add": [_p, _p, _p, _p, _i] + [_i] * 14 + [_p],
     "sdhip_conv2d_fwd_bnbwd": [_p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _i] + [_i] * 17 + [_p],

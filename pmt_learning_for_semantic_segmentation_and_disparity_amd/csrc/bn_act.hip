@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* gy, int 
                                                                const float* __restrict__ dshift, int nrep,
                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, int acc_par, int C, long npix_g,
+                                                               float* __restrict__ dbeta, int acc_par, float pscale, int C, long npix_g,
                                                                double inv_count, int act, const double* __restrict__ dsum, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
   __shared__ float s_a[64 * 8], s_b2[64 * 8];
@@ -375,7 +375,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* gy, int 
         }
       }
     }
-    if (writer && rl == 0 && okc) {
+    if (writer && rl == 0 && okc) {      // pscale = 1 / world size when the sums are global (the gradient all-reduce adds the ranks' shares)
+      dg *= pscale; db *= pscale;
       dgamma[c] = acc_par ? dgamma[c] + dg : dg;
       dbeta[c] = acc_par ? dbeta[c] + db : db;
     }
@@ -802,7 +803,7 @@ extern "C" int sdhip_affine_act_bn(const void* x, int ldx, void* y, int ldy, con
 static int bn_bwd_apply_fin_impl(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
                                  const float* scale, const float* shift, const float* dscale, const float* dshift, const double* dsum, int nrep,
                                       const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                                      int accumulate_params, long npix, int C, int groups, double count, int act, int dtype,
+                                      int accumulate_params, float param_scale, long npix, int C, int groups, double count, int act, int dtype,
                                       void* stream) {
   if (nrep < 1) nrep = 1;
   const int G = groups;
@@ -813,7 +814,7 @@ static int bn_bwd_apply_fin_impl(const void* gy, int ldg, const void* x, int ldx
                   "bn_bwd_apply_fin: bad arguments");
   hipStream_t s = (hipStream_t)stream;
 #define ARGS(T) (const T*)gy, ldg, (const T*)x, ldx, (T*)gx, ldgx, scale, shift, dscale, dshift, nrep, gamma, mean, invstd, \
-                dgamma, dbeta, accumulate_params, C, npix / G, 1.0 / count, act, dsum
+                dgamma, dbeta, accumulate_params, param_scale, C, npix / G, 1.0 / count, act, dsum
   if (dtype == SDHIP_F32) {
     const bool v = vec_rows<float>(C, {ldg, ldx, ldgx}, {gy, x, gx});
     Plan pl = plan(v ? C / 4 : C, npix / G, G, tune_fused_blocks());
@@ -833,10 +834,10 @@ static int bn_bwd_apply_fin_impl(const void* gy, int ldg, const void* x, int ldx
 extern "C" int sdhip_bn_bwd_apply_fin(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
                                       const float* scale, const float* shift, const float* dscale, const float* dshift, int nrep,
                                       const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                                      int accumulate_params, long npix, int C, int groups, double count, int act, int dtype,
+                                      int accumulate_params, float param_scale, long npix, int C, int groups, double count, int act, int dtype,
                                       void* stream) {
   return bn_bwd_apply_fin_impl(gy, ldg, x, ldx, gx, ldgx, scale, shift, dscale, dshift, nullptr, nrep, gamma, mean, invstd, dgamma, dbeta,
-                               accumulate_params, npix, C, groups, count, act, dtype, stream);
+                               accumulate_params, param_scale, npix, C, groups, count, act, dtype, stream);
 }
 
 // ... with the two reductions given as f64 [nrep][groups][2][C] (sum(gm*x), sum(gm)): the layout the epilogue of
@@ -844,10 +845,10 @@ extern "C" int sdhip_bn_bwd_apply_fin(const void* gy, int ldg, const void* x, in
 extern "C" int sdhip_bn_bwd_apply_fin_d(const void* gy, int ldg, const void* x, int ldx, void* gx, int ldgx,
                                         const float* scale, const float* shift, const double* sums, int nrep,
                                         const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                                        int accumulate_params, long npix, int C, int groups, double count, int act, int dtype,
+                                        int accumulate_params, float param_scale, long npix, int C, int groups, double count, int act, int dtype,
                                         void* stream) {
   return bn_bwd_apply_fin_impl(gy, ldg, x, ldx, gx, ldgx, scale, shift, nullptr, nullptr, sums, nrep, gamma, mean, invstd, dgamma, dbeta,
-                               accumulate_params, npix, C, groups, count, act, dtype, stream);
+                               accumulate_params, param_scale, npix, C, groups, count, act, dtype, stream);
 }
 
 extern "C" int sdhip_channel_stats(const void* x, int ldx, double* stats, int ldc, int nrep, long npix, int C, int groups,
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(256) void stats_fix_fin_kernel(const T* gin, int ld
                                                             const float* __restrict__ dscale, const float* __restrict__ dshift, int nrep,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int acc_par, int Cf, int G, double inv_count) {
+                                                            float* __restrict__ dbeta, int acc_par, float pscale, int Cf, int G, double inv_count) {
   constexpr int N = Unit<T, true>::N;
   __shared__ float red[2][8][32];
   __shared__ float fa[32], fb[32];
@@ -948,6 +949,7 @@ __global__ __launch_bounds__(256) void stats_fix_fin_kernel(const T* gin, int ld
       }
     }
     if (rl == 0 && okc) {
+      dg *= pscale; db *= pscale;                    // (see bn_bwd_apply_fin_kernel)
       dgamma[c] = acc_par ? dgamma[c] + dg : dg;
       dbeta[c] = acc_par ? dbeta[c] + db : db;
     }
@@ -998,7 +1000,7 @@ __global__ __launch_bounds__(256) void stats_fix_fin_kernel(const T* gin, int ld
 extern "C" int sdhip_stats_fix_fin(const void* gin, int ldgi, const void* x, int ldx, void* gout, int ldgo, long npix,
                                    double* dS, int ldc, int cs, const float* dscale, const float* dshift, int nrep,
                                    const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                                   int accumulate_params, int Cf, int groups, double count, int dtype, void* stream) {
+                                   int accumulate_params, float param_scale, int Cf, int groups, double count, int dtype, void* stream) {
   const int G = groups;
   if (int rc = check_rows("stats_fix_fin", npix, 32, G, dtype)) return rc;
   SDHIP_CHECK_ARG(gin && x && gout && dS && dscale && dshift && gamma && mean && invstd && dgamma && dbeta && ldgi >= 32 && ldx >= 32 &&
@@ -1006,7 +1008,7 @@ extern "C" int sdhip_stats_fix_fin(const void* gin, int ldgi, const void* x, int
   hipStream_t s = (hipStream_t)stream;
   const int nfb = sdhip_cdiv(Cf, 32);
 #define ARGS(T) (const T*)gin, ldgi, (const T*)x, ldx, (T*)gout, ldgo, npix / G, pl.rg, dS, ldc, cs, dscale, dshift, nrep, gamma, mean, invstd, \
-                dgamma, dbeta, accumulate_params, Cf, G, 1.0 / count
+                dgamma, dbeta, accumulate_params, param_scale, Cf, G, 1.0 / count
   if (dtype == SDHIP_F32) {
     SDHIP_CHECK_ARG((vec_rows<float>(32, {ldgi, ldx, ldgo}, {gin, x, gout})), "stats_fix_fin: rows must be 16-byte aligned");
     Plan pl = plan(32 / 4, npix / G, G);

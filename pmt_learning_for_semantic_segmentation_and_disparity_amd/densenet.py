@@ -42,16 +42,18 @@ def _fold(ws, S_slice, groups, C, Ct):
     call("sdhip_stats_replica_sum", ptr(ws), ptr(S_slice), nrep, groups, C, C, Ct, stream_ptr())
 
 
-def _fold_finalize(ws, c_new0, Cn, S, Ct, bn, C, count, groups):
+def _fold_finalize(ws, c_new0, Cn, S, Ct, bn, C, count, groups, synced=False):
     """sdhip_bn_fold_finalize: (scale, shift, mean, invstd) of `bn` over the first C slab channels, folding the replicas `ws`
     of the Cn newest channels (at c_new0) into the slab statistics S on the way (single GPU: no exchange in between)."""
     dev = bn.weight.device
     out = [torch.empty((groups, C), dtype=torch.float32, device=dev) for _ in range(4)]
     ops._bn_track(bn, groups)
     mom = 0.1 if bn.momentum is None else bn.momentum
+    if not synced:
+        ops.parallel.all_reduce_sum_(ws)          # sync-BN: the newest channels' replica sums become global in place
     call("sdhip_bn_fold_finalize", ptr(ws), ws.shape[0], ws.stride(-2), c_new0, Cn, ptr(S), Ct, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
-         ptr(bn.running_var), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, groups, float((count)), float(bn.eps), float(mom),
-         stream_ptr())
+         ptr(bn.running_var), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, groups, float(ops.parallel.global_count(count)),
+         float(bn.eps), float(mom), stream_ptr())
     return out
 
 
@@ -96,7 +98,8 @@ class _DenseBlockFn(torch.autograd.Function):
             _fold(ws0, S[:, :, :C0], groups, C0, Ct)
         saved = []
         pending = None      # (replicas of the previous layer's new channels, their channel offset): folded by the next finalize
-        fuse = training and ops.parallel.world_size() == 1
+        fuse = training        # (also under data parallelism: the exchanges are in-place all-reduces between producer and consumer)
+        gcount = ops.parallel.global_count(count)
         small = fuse and npix <= PRO_MAX_PIX and not _lib_mod.DIAG_NO_BNPRO   # finalize kernels folded into the convolutions
         nrep3 = 2 if small else NREP                      # replicas of a layer's output statistics (read back by <= 4 at a time)
         for li, layer in enumerate(layers):
@@ -114,12 +117,15 @@ class _DenseBlockFn(torch.autograd.Function):
                 # ... and norm1's finalize (with the fold of the previous layer's statistics into the slab's) inside conv1's
                 bn1 = layer.norm1
                 sc1, sh1, mu1, iv1 = [torch.empty((groups, Cin), dtype=torch.float32, device=dev) for _ in range(4)]
-                pw, pc0 = (pending if pending is not None else (None, 0))
+                pw, pc0 = (pending[:2] if pending is not None else (None, 0))
+                if pw is not None and not pending[2]:
+                    ops.parallel.all_reduce_sum_(pw)     # the previous layer's output statistics (folded into the slab's by this launch)
+                    pending = (pw, pc0, True)
                 rc = _lib_mod._lib.sdhip_conv2d_fwd_bnpro(
                     ptr(slab), ptr(w1), ptr(y1), ptr(S2), S2.stride(-2), nrep2, ptr(S), Ct, 1,
                     ptr(pw), pw.stride(-2) if pw is not None else 0, pw.shape[0] if pw is not None else 0, pc0, growth if pw is not None else 0,
                     ptr(bn1.weight), ptr(bn1.bias), ptr(bn1.running_mean), ptr(bn1.running_var), ptr(sc1), ptr(sh1), ptr(mu1), ptr(iv1),
-                    float(count), float(bn1.eps), float(0.1 if bn1.momentum is None else bn1.momentum),
+                    float(gcount), float(bn1.eps), float(0.1 if bn1.momentum is None else bn1.momentum),
                     B, H, W, Cin, Ct, H, W, mid, mid, 1, 1, 0, 0, groups, dt, stream_ptr())
                 if rc == 0:
                     ops._bn_track(bn1, groups)
@@ -129,7 +135,7 @@ class _DenseBlockFn(torch.autograd.Function):
             if not done1:
                 if pending is not None:
                     # ONE launch: fold the previous layer's statistics into the slab AND finalize this layer's norm1
-                    sc1, sh1, mu1, iv1 = _fold_finalize(pending[0], pending[1], growth, S, Ct, layer.norm1, Cin, count, groups)
+                    sc1, sh1, mu1, iv1 = _fold_finalize(pending[0], pending[1], growth, S, Ct, layer.norm1, Cin, count, groups, pending[2])
                     pending = None
                 else:
                     sc1, sh1, mu1, iv1 = _finalize(S[:, :, :Cin], 1, layer.norm1, count, groups, training, synced=True)
@@ -137,14 +143,16 @@ class _DenseBlockFn(torch.autograd.Function):
                                  True, groups, 0, False, nrep2)
             w2 = ops.packed_weight(layer.conv2.weight, 'conv', 'fwd', dtype)
             S3 = ops._zeros((nrep3, groups, 2, growth), torch.float64, dev)[0] if training else None
-            done2 = False
+            done2 = s2_synced = False
             if pro2:
                 bn2 = layer.norm2
                 sc2, sh2, mu2, iv2 = [torch.empty((groups, mid), dtype=torch.float32, device=dev) for _ in range(4)]
+                ops.parallel.all_reduce_sum_(S2)         # sync-BN: conv1's epilogue sums, in place, before conv2 finalizes them
+                s2_synced = True
                 rc = _lib_mod._lib.sdhip_conv2d_fwd_bnpro(
                     ptr(y1), ptr(w2), ptr(slab[:, Cin:Cin + growth]), ptr(S3), S3.stride(-2), nrep3, ptr(S2), S2.stride(-2), nrep2,
                     None, 0, 0, 0, 0, ptr(bn2.weight), ptr(bn2.bias), ptr(bn2.running_mean), ptr(bn2.running_var), ptr(sc2), ptr(sh2), ptr(mu2), ptr(iv2),
-                    float(count), float(bn2.eps), float(0.1 if bn2.momentum is None else bn2.momentum),
+                    float(gcount), float(bn2.eps), float(0.1 if bn2.momentum is None else bn2.momentum),
                     B, H, W, mid, mid, H, W, growth, Ct, 3, 3, 1, 1, groups, dt, stream_ptr())
                 if rc == 0:
                     ops._bn_track(bn2, groups)
@@ -152,12 +160,12 @@ class _DenseBlockFn(torch.autograd.Function):
                 elif rc != _lib_mod.ERR_UNSUPPORTED:
                     raise _lib_mod.SdhipError("sdhip_conv2d_fwd_bnpro failed (%d): %s" % (rc, _lib_mod._lib.sdhip_last_error().decode()))
             if not done2:
-                sc2, sh2, mu2, iv2 = _finalize(S2, nrep2, layer.norm2, count, groups, training)
+                sc2, sh2, mu2, iv2 = _finalize(S2, nrep2, layer.norm2, count, groups, training, synced=s2_synced)
                 ops._conv_launch(y1, mid, w2, slab[:, Cin:Cin + growth], Ct, None, sc2, sh2, S3, B, H, W, mid, H, W, growth,
                                  3, 3, 1, 1, 1, 1, True, groups, 0, False, nrep3)
             if training:   # fold the replicas into this layer's slice of the slab statistics
                 if fuse and li + 1 < L:
-                    pending = (S3, Cin)          # ... together with the next layer's norm1 finalize
+                    pending = (S3, Cin, False)   # ... together with the next layer's norm1 finalize (False: not yet summed over ranks)
                 else:
                     _fold(S3, S[:, :, Cin:Cin + growth], groups, growth, Ct)
             saved.append((y1, sc1, sh1, mu1, iv1, sc2, sh2, mu2, iv2))
@@ -180,7 +188,9 @@ class _DenseBlockFn(torch.autograd.Function):
         call("sdhip_affine_act", ptr(gv), ldg, ptr(g_slab), Ct, None, 0, None, None, npix, Ct, 1, 0, dt, st)
         dS = gS_in.clone() if gS_in is not None else torch.zeros((groups, 2, Ct), dtype=torch.float64, device=dev)
         grads = []
-        fuse = training and growth == 32 and ops.parallel.world_size() == 1
+        fuse = training and growth == 32
+        gcount = ops.parallel.global_count(count)     # sync-BN: the replica sums below are all-reduced in place before they are consumed
+        pscale = ops.parallel.param_scale()
         pend = None    # norm1 backward sums of the layer processed last, finalized together with this layer's stats_fix
         for li in range(len(layers) - 1, -1, -1):
             layer = layers[li]
@@ -194,7 +204,7 @@ class _DenseBlockFn(torch.autograd.Function):
                 # ... in the same launch as the per-channel finalize of the layer above (sdhip_stats_fix_fin)
                 dsc, dsh, nl, dgam, dbet, direct, Cf = pend
                 call("sdhip_stats_fix_fin", ptr(sl_g), Ct, ptr(sl_x), Ct, ptr(dy2), growth, npix, ptr(dS), Ct, Cin, ptr(dsc), ptr(dsh), NREP,
-                     ptr(nl[0]), ptr(nl[1]), ptr(nl[2]), ptr(dgam), ptr(dbet), int(direct), Cf, groups, float(count), dt, st)
+                     ptr(nl[0]), ptr(nl[1]), ptr(nl[2]), ptr(dgam), ptr(dbet), int(direct), pscale, Cf, groups, float(gcount), dt, st)
                 pend = None
             else:
                 call("sdhip_stats_fix", ptr(sl_g), Ct, ptr(sl_x), Ct, ptr(dy2), growth, ptr(dS[:, :, Cin:Cin + growth]), Ct,
@@ -218,14 +228,15 @@ class _DenseBlockFn(torch.autograd.Function):
                 direct2 = tg is not None and tb is not None
                 dg2 = tg if direct2 else torch.empty(mid, dtype=torch.float32, device=dev)
                 db2 = tb if direct2 else torch.empty(mid, dtype=torch.float32, device=dev)
+                ops.parallel.all_reduce_sum_(sums2)
                 call("sdhip_bn_bwd_apply_fin_d", ptr(gp2), mid, ptr(y1), mid, ptr(gp2), mid, ptr(sc2), ptr(sh2), ptr(sums2), NREP,
-                     ptr(layer.norm2.weight), ptr(mu2), ptr(iv2), ptr(dg2), ptr(db2), int(direct2), npix, mid, groups, float(count),
+                     ptr(layer.norm2.weight), ptr(mu2), ptr(iv2), ptr(dg2), ptr(db2), int(direct2), pscale, npix, mid, groups, float(gcount),
                      1, dt, st)
                 if direct2:
                     dg2 = db2 = None
             elif training and ops._fused_bn():
                 dg2, db2 = ops.bn_backward_two_phase(gp2, mid, y1, mid, gp2, mid, sc2, sh2, mu2, iv2, layer.norm2.weight,
-                                                     layer.norm2.bias, npix, mid, groups, 1, count, dt)   # in place: elementwise
+                                                     layer.norm2.bias, npix, mid, groups, 1, gcount, dt)   # in place: elementwise
             else:
                 dg2, db2, dS2 = ops._bn_backward(gp2, mid, y1, mid, gp2, mid, sc2, sh2, mu2, iv2, layer.norm2.weight, npix, mid,
                                                  groups, 1, count, training, dt, beta=layer.norm2.bias)
@@ -257,6 +268,7 @@ class _DenseBlockFn(torch.autograd.Function):
                 if not fused1:
                     call("sdhip_affine_act_bwd", ptr(gp1), Cin, ptr(slab), Ct, ptr(g_slab), Ct, ptr(sc1), ptr(sh1), ptr(both[0]), ptr(both[1]),
                          NREP, npix, Cin, groups, 1, 1, int(pz), dt, st)
+                ops.parallel.all_reduce_sum_(both)        # norm1's two reductions [2][NREP][groups][Cin]: global before the finalize
                 tg, tb = ops._grad_target(layer.norm1.weight), ops._grad_target(layer.norm1.bias)
                 direct = tg is not None and tb is not None
                 dgam = tg if direct else torch.empty(Cin, dtype=torch.float32, device=dev)

@@ -365,8 +365,13 @@ from . import parallel  # noqa: E402
 
 
 def _sync_stats(stats, nrep):
-    """Data parallel: fold the replicas, all-reduce the compact f64 (sum, sum of squares) over ranks (sync-BN)."""
+    """Data parallel: all-reduce the f64 (sum, sum of squares) over ranks (sync-BN) — in place on the replica buffer when it
+    is dense (the replicas are folded by whoever consumes the buffer, as on one GPU); a strided view is folded into a
+    compact copy first."""
     if stats is None or parallel.world_size() == 1:
+        return stats, nrep
+    if stats.is_contiguous():
+        parallel.all_reduce_sum_(stats)
         return stats, nrep
     G, _, C = stats.shape[-3:]
     compact, pz = _zeros((G, 2, C), torch.float64, stats.device)   # zero arena of the step: no fill launch per layer
@@ -406,8 +411,9 @@ def _bn_finalize(stats, nrep, bn, count, groups, synced=False):
 
 
 def _fused_bn():
-    """Consumer-side finalize kernels: single-GPU only (the sync-BN exchange sits between reduction and finalize)."""
-    return parallel.world_size() == 1 and not _lib.DIAG_NO_FUSED_BN
+    """Consumer-side finalize kernels.  They also serve under data parallelism: the sync-BN exchange all-reduces the
+    producer's replica buffer in place, between the launch that fills it and the launch that consumes it."""
+    return not _lib.DIAG_NO_FUSED_BN
 
 
 def _bn_track(bn, groups):
@@ -423,21 +429,23 @@ def _bn_track(bn, groups):
 
 
 def bn_backward_two_phase(gy, ldg, x, ldx, gx, ldgx, scale, shift, mean, invstd, gamma, beta, npix, C, groups, act, count, dt):
-    """Train-mode backward of y = act(BatchNorm(x)) on one GPU: (1) reductions only, (2) ONE pass that derives the
-    statistics gradient from the replica sums itself and writes the complete gradient of x (+ dgamma / dbeta).
+    """Train-mode backward of y = act(BatchNorm(x)): (1) reductions only, [data parallel: the replica sums are all-reduced
+    in place], (2) ONE pass that derives the statistics gradient from the replica sums itself and writes the complete
+    gradient of x (+ dgamma / dbeta).  `count`: the global element count per group.
     Returns (dgamma, dbeta), each None when accumulated straight into the flat gradient buffer."""
     dev = scale.device
     both, pz = _zeros((2, NREP, groups, C), torch.float32, dev)
     dsc, dsh = both[0], both[1]
     call("sdhip_affine_act_bwd", ptr(gy), ldg, ptr(x), ldx, None, 0, ptr(scale), ptr(shift), ptr(dsc), ptr(dsh), NREP,
          npix, C, groups, act, 0, int(pz), dt, stream_ptr())
+    parallel.all_reduce_sum_(both)            # sync-BN: the replica sums become global in place (`count` is the global count)
     tg, tb = _grad_target(gamma), _grad_target(beta)
     direct = tg is not None and tb is not None
     dgamma = tg if direct else torch.empty(C, dtype=torch.float32, device=dev)
     dbeta = tb if direct else torch.empty(C, dtype=torch.float32, device=dev)
     call("sdhip_bn_bwd_apply_fin", ptr(gy), ldg, ptr(x), ldx, ptr(gx), ldgx, ptr(scale), ptr(shift), ptr(dsc), ptr(dsh), NREP,
-         ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), int(direct), npix, C, groups, float(count), act, dt,
-         stream_ptr())
+         ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), int(direct), parallel.param_scale(), npix, C, groups,
+         float(count), act, dt, stream_ptr())
     return (None, None) if direct else (dgamma, dbeta)
 
 
@@ -463,9 +471,8 @@ def _bn_backward(gy, ldg, x, ldx, gx, ldgx, scale, shift, mean, invstd, gamma, n
         # sync-BN backward: dgamma/dbeta from the LOCAL sums, the statistics gradient from the GLOBAL sums
         call("sdhip_bn_finalize_bwd", ptr(dsc), ptr(dsh), NREP, ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
              None, C, par_flag, C, groups, float(count), 1, stream_ptr())
-        glob = both.sum(1)                                     # [2][groups][C]: one launch folds the replicas of both sums
-        parallel.all_reduce_sum_(glob)
-        call("sdhip_bn_finalize_bwd", ptr(glob[0]), ptr(glob[1]), 1, ptr(gamma), ptr(mean), ptr(invstd), None, None,
+        parallel.all_reduce_sum_(both)                         # [2][NREP][groups][C] in place: the finalize folds the replicas
+        call("sdhip_bn_finalize_bwd", ptr(dsc), ptr(dsh), NREP, ptr(gamma), ptr(mean), ptr(invstd), None, None,
              ptr(dstats), dstats.stride(-2), int(accumulate_dstats), C, groups, float(parallel.global_count(count)), 1,
              stream_ptr())
         return (None, None, dstats) if direct else (dgamma, dbeta, dstats)
@@ -713,10 +720,11 @@ class _ConvBNActFn(torch.autograd.Function):
             # one launch: every workgroup derives scale/shift of its channels from the statistics the conv just wrote
             scale, shift, mean, invstd = [torch.empty((groups, Cout), dtype=torch.float32, device=x.device) for _ in range(4)]
             _bn_track(bn, groups)
+            parallel.all_reduce_sum_(ws)         # sync-BN: the conv epilogue's replica sums become global, in place
             call("sdhip_affine_act_bn", ptr(yraw), ldr_, ptr(y), ldy, ptr(rv), ldr, ptr(ws), ws.stride(-2), NREP, ptr(bn.weight),
                  ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                 B * spec.Ho * spec.Wo, Cout, groups, float(count), float(bn.eps), float(0.1 if bn.momentum is None else bn.momentum),
-                 act, dtype_code(x), stream_ptr())
+                 B * spec.Ho * spec.Wo, Cout, groups, float(parallel.global_count(count)), float(bn.eps),
+                 float(0.1 if bn.momentum is None else bn.momentum), act, dtype_code(x), stream_ptr())
         else:
             scale, shift, mean, invstd = _bn_finalize(ws, NREP, bn, count, groups)
             call("sdhip_affine_act", ptr(yraw), ldr_, ptr(y), ldy, ptr(rv), ldr, ptr(scale), ptr(shift), B * spec.Ho * spec.Wo,
@@ -747,15 +755,16 @@ class _ConvBNActFn(torch.autograd.Function):
             direct = tg is not None and tb is not None
             dgamma = tg if direct else torch.empty(Cout, dtype=torch.float32, device=xv.device)
             dbeta = tb if direct else torch.empty(Cout, dtype=torch.float32, device=xv.device)
+            parallel.all_reduce_sum_(ob.sums)
             call("sdhip_bn_bwd_apply_fin_d", ptr(g), ldg, ptr(yraw), ldraw, ptr(graw), ldgr, ptr(scale), ptr(shift), ptr(ob.sums), NREP,
-                 ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), int(direct), npix, Cout, groups, float(ctx.count),
-                 ctx.act, dt, stream_ptr())
+                 ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), int(direct), parallel.param_scale(), npix, Cout, groups,
+                 float(parallel.global_count(ctx.count)), ctx.act, dt, stream_ptr())
             if direct:
                 dgamma = dbeta = None
             ob.sums, ob.gptr = None, 0
         elif ctx.train and ctx.act in (0, 1, 2) and _fused_bn():
             dgamma, dbeta = bn_backward_two_phase(g, ldg, yraw, ldraw, graw, ldgr, scale, shift, mean, invstd, gamma, beta, npix,
-                                                  Cout, groups, ctx.act, ctx.count, dt)
+                                                  Cout, groups, ctx.act, parallel.global_count(ctx.count), dt)
         elif ctx.train and ctx.act in (0, 1, 2):
             # two-phase: reductions only (no gradient written), per-channel finalize, then ONE pass writes the complete
             # gradient of the conv output — 10 bytes per element instead of 12
@@ -1564,10 +1573,11 @@ class _Deconv3dS2BNActFn(torch.autograd.Function):
         if train and _fused_bn():
             scale, shift, mean, invstd = [torch.empty((groups, Cout), dtype=torch.float32, device=x.device) for _ in range(4)]
             _bn_track(bn, groups)
+            parallel.all_reduce_sum_(ws)
             call("sdhip_affine_act_bn", ptr(yraw), ldr_, ptr(y), ldy, ptr(rv), ldr, ptr(ws), ws.stride(-2), NREP, ptr(bn.weight),
                  ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                 Bo * 4 * H * W, Cout, groups, float(count), float(bn.eps), float(0.1 if bn.momentum is None else bn.momentum),
-                 act, dtype_code(x), stream_ptr())
+                 Bo * 4 * H * W, Cout, groups, float(parallel.global_count(count)), float(bn.eps),
+                 float(0.1 if bn.momentum is None else bn.momentum), act, dtype_code(x), stream_ptr())
         else:
             scale, shift, mean, invstd = _bn_finalize(ws, NREP, bn, count, groups)
             call("sdhip_affine_act", ptr(yraw), ldr_, ptr(y), ldy, ptr(rv), ldr, ptr(scale), ptr(shift), Bo * 4 * H * W,
@@ -1590,7 +1600,7 @@ class _Deconv3dS2BNActFn(torch.autograd.Function):
         graw, ldgr = alloc_nhwc(Bo, Cout, Ho, Wo, xv.dtype, xv.device)
         if train and act in (0, 1, 2) and _fused_bn():
             dgamma, dbeta = bn_backward_two_phase(g, ldg, yraw, ldraw, graw, ldgr, scale, shift, mean, invstd, gamma, beta, npix,
-                                                  Cout, groups, act, count, dt)
+                                                  Cout, groups, act, parallel.global_count(count), dt)
         elif train and act in (0, 1, 2):
             dgamma, dbeta, dS = _bn_backward(g, ldg, yraw, ldraw, None, 0, scale, shift, mean, invstd, gamma, npix, Cout,
                                              groups, act, count, True, dt, beta=beta)

@@ -218,6 +218,51 @@ def gen_nets():
     save("nets", **arrays)
 
 
+def gen_minidsnet():
+    """`sdnet_mini` (models/dsnet_t2.py:825-913, util/utilLoadNetwork.py:10) train + eval, and the edge-channel variants
+    (`-edges 1`: 4-channel inputs, include_edges=True) of minidsnet (2-D correlation) and minidsnetExt, eval."""
+    from models import dsnet_t2 as D
+    arrays = {}
+    cases = [("mini", "minidsnet", '1dcorr', False, ("train", "eval")), ("mini_edges_2d", "minidsnet", '', True, ("eval",)),
+             ("ext_edges", "minidsnetExt", '1dcorr', True, ("eval",))]
+    for tag, cls, patch, edges, modes in cases:
+        def make(mod):
+            if cls == "minidsnet":
+                return mod.minidsnet(R.CFG(), labels=2, pretrained=False, patch_type=patch, include_edges=edges)
+            kw = dict(backbone='densenet') if mod is D else {}
+            return mod.minidsnetExt(R.CFG(aspp=0), labels=2, pretrained=False, patch_type=patch, include_edges=edges, **kw)
+        for mode in modes:
+            ref = fill_state_dict(make(D), 33)
+            ref.train() if mode == "train" else ref.eval()
+            nc = 4 if edges else 3
+            a, b = rand_input(33, "left", (2, nc, 256, 256)), rand_input(33, "right", (2, nc, 256, 256))
+            seg = F.one_hot((rand_input(33, "seg", (2, 256, 256)) > 0.5).long(), 2).permute(0, 3, 1, 2).float()
+            disp = rand_input(33, "disp", (2, 1, 256, 256), 0.0, 8.0)
+            outs = ref(a, b)
+            loss = train_loss(outs, seg, disp)
+            loss.backward()
+            p = "%s.%s" % (tag, mode)
+            names = ("seg1", "disp") if cls == "minidsnet" else ("seg1", "disp", "seg2")
+            for i, name in enumerate(names):
+                arrays.update(flat("%s.%s" % (p, name), sample(outs[i], 8)))
+            arrays["%s.loss" % p] = np.float64(loss.item())
+            for k, v in grad_norms(ref).items():
+                arrays["%s.gnorm.%s" % (p, k)] = v
+            if mode == "train":
+                bn = ref.conv2d_ba3[0].layers[1]      # an auxiliary branch nothing consumes: its statistics still move
+                arrays["%s.rm.ba3" % p] = bn.running_mean.numpy().copy()
+                arrays["%s.rv.ba3" % p] = bn.running_var.numpy().copy()
+            mine = make(R)
+            mine.load_state_dict(fill_state_dict(make(D), 33).state_dict())
+            mine.train() if mode == "train" else mine.eval()
+            for x, y in zip(mine(a, b), outs):
+                err = float((x - y).abs().max())
+                assert err < 2e-4, (tag, mode, err)
+            print(tag, mode, "oracle==reference, loss", loss.item())
+    arrays["meta.corr"] = np.array("assumed-semantics")
+    save("minidsnet", **arrays)
+
+
 def _pos(B, H, W):
     """The position maps of util/torch_implementation.py:139-143 at a reduced size (row index // 8 semantics kept:
     values 0..127 over the image height)."""
@@ -330,6 +375,9 @@ def gen_keys():
         "mini_a2_hanet": lambda: D.minidsnetExt(R.CFG(aspp=2, hanet=1), labels=19, pretrained=False, patch_type='1dcorr', backbone='densenet'),
         "dsnet": lambda: D.dsnet(R.CFG(), labels=2, pretrained=False),
         "psmnet192": lambda: SH.PSMNet(192),
+        "minidsnet": lambda: D.minidsnet(R.CFG(), labels=2, pretrained=False, patch_type='1dcorr'),
+        "mini_a0_edges": lambda: D.minidsnetExt(R.CFG(aspp=0), labels=2, pretrained=False, patch_type='1dcorr', include_edges=True,
+                                                backbone='densenet'),
     }
     out = {}
     for name, ctor in nets.items():
@@ -717,7 +765,10 @@ if __name__ == "__main__":
     _install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet", "hanet", "metrics", "keys", "data", "losses", "dsnetnocorr", "syncbn", "cfg5"]
+    which = sys.argv[1:] or ["ops", "backbone", "nets", "psmnet", "dsnet", "hanet", "metrics", "keys", "data", "losses", "dsnetnocorr", "syncbn", "cfg5",
+                             "minidsnet"]
+    if "minidsnet" in which:
+        gen_minidsnet()
     if "losses" in which:
         gen_losses()
     if "syncbn" in which:

@@ -466,7 +466,8 @@ class minidsnetExt(nn.Module):
 
     def __init__(self, CFG, labels=8, pretrained=False, patch_type='', include_edges=False, backbone='densenet'):
         super().__init__()
-        assert backbone == 'densenet' and not CFG.multaskloss and not include_edges
+        assert backbone == 'densenet' and not CFG.multaskloss
+        self.include_edges = include_edges
         self.hanet = CFG.hanet
         dropout = CFG.dropout
         self.aspp_mod, self.use_att, self.convDeconvOut, self.abilation = CFG.aspp, CFG.use_att, CFG.convDeconvOut, CFG.abilation
@@ -477,8 +478,8 @@ class minidsnetExt(nn.Module):
         elif self.aspp_mod == 2:
             self.aspp, inplane_seg2, feature_channel = build_aspp('densenet_a3', 32), 273, 64
         self.resnet_features = piramidNet2(pretrained, backbone)
-        for j in range(4):
-            setattr(self, 'conv2d_ba%d' % j, _img_conv(3))
+        for j in range(4):      # aux_img_channel = 4 with the edge map (models/dsnet_t2.py:1061-1069)
+            setattr(self, 'conv2d_ba%d' % j, _img_conv(4 if include_edges else 3))
         patch = (1, 17) if patch_type == '1dcorr' else (17, 17)
         self.correlation_sampler = SpatialCorrelationSampler(1, patch, 1, 0, dilation_patch=1)
         self.s2_corr_sampler = SpatialCorrelationSampler(1, patch, 1, 0, dilation_patch=1)
@@ -520,8 +521,9 @@ class minidsnetExt(nn.Module):
                     m.bias.data.zero_()
 
     def forward(self, input_a, input_b, pos=None, disp_gt=None, seg_gt=None):
-        a = self.resnet_features(input_a)  # a_0..a_4, B2, B1, B0
-        b = self.resnet_features(input_b)
+        left, right = (input_a[:, :3], input_b[:, :3]) if self.include_edges else (input_a, input_b)   # models/dsnet_t2.py:1153-1158
+        a = self.resnet_features(left)  # a_0..a_4, B2, B1, B0
+        b = self.resnet_features(right)
         xl3, xl2 = self.conv2d_ba3(input_a), self.conv2d_ba1(input_a)
         xl1, xl0 = self.conv2d_ba2(input_a), self.conv2d_ba0(input_a)
         x, x1, seg1 = self.segNet(torch.cat([a[4], b[4]], 1), input_a, input_b, xl0)
@@ -574,6 +576,51 @@ class minidsnetExt(nn.Module):
             if self.hanet:
                 seg2, _ = self.hanet_last(a[0], seg2, pos, attention_loss=True)
         return seg1, disp, seg2, disp
+
+
+class minidsnet(nn.Module):
+    """models/dsnet_t2.py:825-913 (`sdnet_mini`): piramidNet pyramid, coarse segmentation head, correlation disparity head."""
+
+    def __init__(self, CFG, labels=8, pretrained=False, patch_type='', include_edges=False):
+        super().__init__()
+        self.patch_type, self.include_edges = patch_type, include_edges
+        self.resnet_features = piramidNet(pretrained=pretrained)
+        for j in range(4):
+            setattr(self, 'conv2d_ba%d' % j, _img_conv(4 if include_edges else 3))
+        patch = (1, 17) if patch_type == '1dcorr' else (17, 17)
+        self.correlation_sampler = SpatialCorrelationSampler(1, patch, 1, 0, dilation_patch=1)
+        self.corrConv2d = _c1x1(patch[0] * patch[1], 128)
+        self.Conv2DownUp3 = Conv2DownUp(32, 128, 3)
+        self.Conv2DownUp4 = Conv2DownUp(256, 64, 3)
+        self.segNet = segNet(2048, 1, labels)
+        self.conv1d_2 = _c1x1(65, 64)
+        self.Conv2DownUp5 = Conv2DownUp(64, 64, 5, lastLayer=False)
+        self.dispoutConv = ConvTranspose2dSame(64, 1, 5, padding='same', init_he=False)
+        self.conv1d_3 = _c1x1(96, 64)
+
+    def forward(self, input_a, input_b):
+        left, right = (input_a[:, :3], input_b[:, :3]) if self.include_edges else (input_a, input_b)
+        a = self.resnet_features(left)      # a_0..a_4, pyramid over tap 2, pyramid over tap 0
+        b = self.resnet_features(right)
+        self.conv2d_ba3(input_a)            # computed and unused upstream (:868,870): their BatchNorm running statistics move
+        xl2 = self.conv2d_ba1(input_a)
+        self.conv2d_ba2(input_a)
+        xl0 = self.conv2d_ba0(input_a)
+        x, x1, seg1 = self.segNet(torch.cat([a[4], b[4]], 1), input_a, input_b, xl0)
+        y = self.correlation_sampler(a[5], b[5])
+        if self.patch_type == '1dcorr':
+            y = torch.squeeze(y, 1)
+        else:
+            n, ph, pw, h, w = y.shape
+            y = y.reshape(n, ph * pw, h, w) / a[5].size(1)
+        y = self.corrConv2d(y)
+        y1 = F.interpolate(self.Conv2DownUp3(x1), size=y.shape[2:], mode='bilinear')
+        y = self.Conv2DownUp4(torch.cat((y1, y), 1))
+        y2 = F.interpolate(y, scale_factor=8)
+        xl2 = F.interpolate(xl2, size=y2.shape[2:], mode='bilinear')
+        d = self.dispoutConv(self.Conv2DownUp5(self.conv1d_2(torch.cat((y2, xl2), 1))))
+        disp = F.interpolate(d, size=left.shape[2:], mode='bilinear')
+        return seg1, disp, seg1, disp
 
 
 # --------------------------------------------------------------------------- PSMNet (models_psmnet/*)

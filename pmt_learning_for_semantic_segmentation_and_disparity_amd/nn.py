@@ -290,8 +290,9 @@ class minidsnetExt(nn.Module):
 
     def __init__(self, CFG, labels=8, pretrained=False, patch_type='', include_edges=False, backbone='densenet'):
         super().__init__()
-        if backbone != 'densenet' or CFG.multaskloss or include_edges:
-            raise NotImplementedError("native path: densenet backbone, no multitask loss / edge channel yet")
+        if backbone != 'densenet' or CFG.multaskloss:
+            raise NotImplementedError("native path: densenet backbone, no multitask loss wrapper (models/dsnet_t2.py:1297) yet")
+        self.include_edges = include_edges
         self.hanet = CFG.hanet
         dropout = CFG.dropout
         self.aspp_mod, self.use_att, self.convDeconvOut, self.abilation = CFG.aspp, CFG.use_att, CFG.convDeconvOut, CFG.abilation
@@ -304,8 +305,8 @@ class minidsnetExt(nn.Module):
             from .aspp import build_aspp
             self.aspp, inplane_seg2, feature_channel = build_aspp('densenet_a3', 32), 273, 64
         self.resnet_features = piramidNet2(pretrained, backbone)
-        for j in range(4):
-            setattr(self, 'conv2d_ba%d' % j, _img_conv(3))
+        for j in range(4):   # the auxiliary image convolutions see the edge map as a 4th channel (models/dsnet_t2.py:1061-1069)
+            setattr(self, 'conv2d_ba%d' % j, _img_conv(4 if include_edges else 3))
         patch = (1, 17) if patch_type == '1dcorr' else (17, 17)
         self.correlation_sampler = SpatialCorrelationSampler(1, patch, 1, 0, dilation_patch=1)
         self.s2_corr_sampler = SpatialCorrelationSampler(1, patch, 1, 0, dilation_patch=1)
@@ -349,13 +350,7 @@ class minidsnetExt(nn.Module):
 
     def forward(self, input_a, input_b, pos=None, disp_gt=None, seg_gt=None):
         B, _, H, W = input_a.shape
-        # both images in one NHWC buffer, channels zero-padded 3 -> 8: one pixel = one 16-byte chunk, so the image convs
-        # (conv0 7x7/2, conv2d_ba* 5x5 dil 2) stage their input with vector loads; the padded weight columns are zero.
-        both8 = torch.zeros((2 * B, H, W, 8), dtype=input_a.dtype, device=input_a.device)
-        both8[:B, :, :, :3] = input_a.permute(0, 2, 3, 1)
-        both8[B:, :, :, :3] = input_b.permute(0, 2, 3, 1)
-        both = both8.permute(0, 3, 1, 2)
-        img_a = both[:B]
+        both, img_a = _stereo_buffer(input_a, input_b, self.include_edges)
         t = self.resnet_features(both, groups=2)          # taps of both towers, batch = [left | right]
         halves = [ops.split_batch(u, B) for u in t]   # left / right tower outputs (one gradient buffer per tap in the backward)
         a = [h[0] for h in halves]
@@ -428,6 +423,23 @@ class minidsnetExt(nn.Module):
         return seg1, disp, seg2, disp
 
 
+def _stereo_buffer(input_a, input_b, include_edges=False):
+    """Both images in one NHWC buffer, channels zero-padded to 8: one pixel = one 16-byte chunk, so the image convolutions
+    (conv0 7x7/2, conv2d_ba* 5x5 dil 2) stage their input with vector loads; the padded weight columns are zero.
+    With include_edges the inputs carry the edge map as a 4th channel (models/dsnet_t2.py:1153-1158): the towers read the
+    first three (their weight has three input channels — the 4th meets zero weight columns), the auxiliary convolutions of
+    the LEFT image all four.  Returns (both towers' batch, left image view)."""
+    B, Cimg, H, W = input_a.shape
+    n = 4 if include_edges else 3
+    if Cimg != n:
+        raise ValueError("expected %d-channel images (include_edges=%s), got %d" % (n, include_edges, Cimg))
+    both8 = torch.zeros((2 * B, H, W, 8), dtype=input_a.dtype, device=input_a.device)
+    both8[:B, :, :, :n] = input_a.permute(0, 2, 3, 1)
+    both8[B:, :, :, :3] = input_b[:, :3].permute(0, 2, 3, 1)
+    both = both8.permute(0, 3, 1, 2)
+    return both, both[:B]
+
+
 def _seq_dropout(mod, x):
     return ops.dropout(x, mod.p, mod.training, _dropout_id(mod)) if mod.p else x
 
@@ -453,6 +465,57 @@ class piramidNet(nn.Module):
         b0 = _pyramid([getattr(self, 'branch0_%d' % j) for j in range(5)], o[0], groups)
         b2 = _pyramid([getattr(self, 'branch1_%d' % j) for j in range(3)], o[2], groups)
         return o[0], o[1], o[2], o[3], o[4], b2, b0
+
+
+class minidsnet(nn.Module):
+    """models/dsnet_t2.py:825-913 (`-net sdnet_mini`, util/utilLoadNetwork.py:10): the first half of minidsnetExt over the
+    `piramidNet` pyramid — coarse segmentation head + correlation-based disparity head.
+    forward(left, right) -> (seg_branch, disp_out, seg_branch, disp_out)."""
+
+    def __init__(self, CFG, labels=8, pretrained=False, patch_type='', include_edges=False, backbone='densenet'):
+        super().__init__()
+        self.patch_type, self.include_edges = patch_type, include_edges
+        self.resnet_features = piramidNet(pretrained=pretrained)
+        for j in range(4):
+            setattr(self, 'conv2d_ba%d' % j, _img_conv(4 if include_edges else 3))
+        patch = (1, 17) if patch_type == '1dcorr' else (17, 17)
+        self.correlation_sampler = SpatialCorrelationSampler(1, patch, 1, 0, dilation_patch=1)
+        self.corrConv2d = _c1x1(patch[0] * patch[1], 128)
+        self.Conv2DownUp3 = Conv2DownUp(32, 128, 3)
+        self.Conv2DownUp4 = Conv2DownUp(256, 64, 3)
+        self.segNet = segNet(2048, 1, labels)
+        self.conv1d_2 = _c1x1(65, 64)
+        self.Conv2DownUp5 = Conv2DownUp(64, 64, 5, lastLayer=False)
+        self.dispoutConv = ConvTranspose2dSame(64, 1, 5, padding='same', init_he=False)
+        self.conv1d_3 = _c1x1(96, 64)          # never called upstream either: kept for the state_dict
+
+    def forward(self, input_a, input_b):
+        B = input_a.shape[0]
+        both, img_a = _stereo_buffer(input_a, input_b, self.include_edges)
+        t = self.resnet_features(both, groups=2)
+        halves = [ops.split_batch(u, B) for u in t]
+        a = [h[0] for h in halves]
+        b = [h[1] for h in halves]
+        xl3 = self.conv2d_ba3[0].fused(img_a, act=1)      # computed (and unused) exactly as in the reference, like xl1
+        xl2 = self.conv2d_ba1[0].fused(img_a, act=1)
+        xl1 = self.conv2d_ba2[0].fused(img_a, act=1)
+        xl0 = self.conv2d_ba0[0].fused(img_a, act=1)
+        del xl3, xl1
+        x, x1, seg1 = self.segNet(ops.concat([a[4], b[4]]), input_a, input_b, xl0)
+        y = self.correlation_sampler(a[5], b[5])
+        if self.patch_type == '1dcorr':
+            y = self.corrConv2d[0].run(torch.squeeze(y, 1), act=1)
+        else:
+            n, ph, pw, h, w = y.shape
+            y = self.corrConv2d[0].run(ops.affine_act(y.reshape(n, ph * pw, h, w), _const(1.0 / a[5].size(1), ph * pw, y.device), None), act=1)
+        y1 = ops.interpolate(self.Conv2DownUp3(x1), size=y.shape[2:], mode='bilinear')
+        y = self.Conv2DownUp4(ops.concat([y1, y]))
+        xl2 = ops.interpolate(xl2, size=(8 * y.shape[2], 8 * y.shape[3]), mode='bilinear')
+        d0 = ops.upcat_conv1x1(y, xl2, self.conv1d_2[0].c2d.weight, act=1)
+        if d0 is None:
+            d0 = self.conv1d_2[0].run(ops.concat([ops.interpolate(y, scale_factor=8), xl2]), act=1)
+        disp = ops.interpolate(self.dispoutConv(self.Conv2DownUp5(d0)), size=input_a.shape[2:], mode='bilinear')
+        return seg1, disp, seg1, disp
 
 
 class dsnet(nn.Module):

@@ -22,10 +22,12 @@ def _nets():
             "mini_a1": lambda: N.minidsnetExt(R.CFG(aspp=1), labels=2, patch_type='1dcorr'),
             "mini_a2_hanet": lambda: N.minidsnetExt(R.CFG(aspp=2, hanet=1), labels=19, patch_type='1dcorr'),
             "dsnet": lambda: N.dsnet(R.CFG(), labels=2),
-            "psmnet192": lambda: P.PSMNet(192)}
+            "psmnet192": lambda: P.PSMNet(192),
+            "minidsnet": lambda: N.minidsnet(R.CFG(), labels=2, patch_type='1dcorr'),
+            "mini_a0_edges": lambda: N.minidsnetExt(R.CFG(aspp=0), labels=2, patch_type='1dcorr', include_edges=True)}
 
 
-@pytest.mark.parametrize("name", ["mini_a0", "mini_a1", "mini_a2_hanet", "dsnet", "psmnet192"])
+@pytest.mark.parametrize("name", ["mini_a0", "mini_a1", "mini_a2_hanet", "dsnet", "psmnet192", "minidsnet", "mini_a0_edges"])
 def test_state_dict_surface_equals_reference(name):
     gold = json.load(open(KEYS))[name]
     m = _nets()[name]()

@@ -296,3 +296,70 @@ def test_hip_densenet_bf16_fused_chain_matches_unfused():
     errs.sort()
     assert errs[len(errs) // 2] < 0.03 and errs[int(len(errs) * 0.9)] < 0.06, (errs[len(errs) // 2], errs[int(len(errs) * 0.9)])
     assert worst < 0.15, worst
+
+
+# ------------------------------------------------------------------ `sdnet_mini` and the edge-channel variants
+MINI_CASES = [("mini", "minidsnet", '1dcorr', False, "train"), ("mini", "minidsnet", '1dcorr', False, "eval"),
+              ("mini_edges_2d", "minidsnet", '', True, "eval"), ("ext_edges", "minidsnetExt", '1dcorr', True, "eval")]
+
+
+def _mini_case(mod, tag, cls, patch, edges, mode):
+    if cls == "minidsnet":
+        m = mod.minidsnet(R.CFG(), labels=2, patch_type=patch, include_edges=edges)
+    else:
+        m = mod.minidsnetExt(R.CFG(aspp=0), labels=2, patch_type=patch, include_edges=edges)
+    m = fill_state_dict(m, 33)
+    nc = 4 if edges else 3
+    a, b = rand_input(33, "left", (2, nc, 256, 256)), rand_input(33, "right", (2, nc, 256, 256))
+    seg = F.one_hot((rand_input(33, "seg", (2, 256, 256)) > 0.5).long(), 2).permute(0, 3, 1, 2).float()
+    return m, a, b, seg, rand_input(33, "disp", (2, 1, 256, 256), 0.0, 8.0)
+
+
+@pytest.mark.parametrize("tag,cls,patch,edges,mode", MINI_CASES[:1] + MINI_CASES[2:3])
+def test_oracle_minidsnet_family_matches_golden(tag, cls, patch, edges, mode):
+    gold = np.load(os.path.join(GDIR, "minidsnet.npz"))
+    m, a, b, seg, disp = _mini_case(R, tag, cls, patch, edges, mode)
+    m.train() if mode == "train" else m.eval()
+    with torch.no_grad():
+        outs = m(a, b)
+    for i, name in enumerate(("seg1", "disp")):
+        _check(gold, "%s.%s.%s" % (tag, mode, name), outs[i], 2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,cls,patch,edges,mode", MINI_CASES)
+def test_hip_minidsnet_family_matches_golden(tag, cls, patch, edges, mode):
+    """`minidsnet` (models/dsnet_t2.py:825-913, FUNCTION_MAP['sdnet_mini']) and the `-edges 1` variants (4-channel inputs,
+    include_edges=True: models/dsnet_t2.py:832-835,863-868,1061-1069,1153-1158) against fixtures captured from the reference:
+    outputs 1e-3, loss 1e-3, gradient norms per top-level module 2-3 %, running statistics of an auxiliary branch whose
+    output nothing consumes (the reference still computes it)."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
+    gold = np.load(os.path.join(GDIR, "minidsnet.npz"))
+    m, a, b, seg, disp = _mini_case(N, tag, cls, patch, edges, mode)
+    m = m.cuda()
+    m.train() if mode == "train" else m.eval()
+    outs = m(a.cuda(), b.cuda())
+    loss = train_loss(outs, seg.cuda(), disp.cuda())
+    loss.backward()
+    p = "%s.%s" % (tag, mode)
+    for i, name in enumerate(("seg1", "disp") if cls == "minidsnet" else ("seg1", "disp", "seg2")):
+        _check(gold, "%s.%s" % (p, name), outs[i], 1e-3)
+    want = float(gold[p + ".loss"])
+    assert abs(loss.item() - want) <= 1e-3 * max(1.0, abs(want))
+    acc = {}
+    for k, q in m.named_parameters():
+        if q.grad is not None:
+            top = k.split(".")[0]
+            acc[top] = acc.get(top, 0.0) + float(q.grad.double().pow(2).sum())
+    checked = 0
+    for top, v in acc.items():
+        key = "%s.gnorm.%s" % (p, top)
+        if key in gold.files:
+            w = float(gold[key])
+            assert abs(np.sqrt(v) - w) <= 3e-2 * max(w, 1e-3), (key, np.sqrt(v), w)
+            checked += 1
+    assert checked >= 8
+    if mode == "train":
+        bn = m.conv2d_ba3[0].layers[1]
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), gold[p + ".rm.ba3"], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), gold[p + ".rv.ba3"], rtol=1e-3, atol=1e-5)

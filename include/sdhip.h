@@ -473,6 +473,7 @@ int sdhip_step_metrics(const void* seg, int lds, const float* seg_target, int ld
  *               depth_big_endian): disparity = depth > 0 ? fb / depth : 0;  SDHIP_DEPTH_U16: uint16 rows, disparity = v/256
  *               then activation: LINEAR none; SIGMOID min(d,max_d)/max_d; TANH d' = min(d,max_d), d' != 0 ? 2d'/max_d-1 : -1
  *               -> out_disp f32 dense out_h x out_w
+ * row_roll (sliceandSwitch, RandomCrop :455-467): output row r is crop row (r + row_roll) mod out_h; 0 = off.
  * Any of the three groups may be NULL.  All pointers are device pointers; mean/std are HOST float[3].
  * ------------------------------------------------------------------------- */
 #define SDHIP_SEG_THRESHOLD 0
@@ -487,7 +488,7 @@ int sdhip_prepare_sample(const unsigned char* left, const unsigned char* right, 
                          const unsigned char* seg, long seg_pitch, int seg_cs, int seg_channel, int seg_mode,
                          int seg_threshold, const unsigned char* lut, const void* depth, long depth_pitch,
                          int depth_mode, int depth_big_endian, int H, int W, int crop_top, int crop_left,
-                         int out_h, int out_w, float fb, float max_d, int activation, const float* mean,
+                         int out_h, int out_w, int row_roll, float fb, float max_d, int activation, const float* mean,
                          const float* stdv, void* out_left, void* out_right, int ld_img, float* out_seg,
                          int ld_seg, int n_seg, float* out_disp, int dtype, void* stream);
 
@@ -497,6 +498,10 @@ int sdhip_prepare_sample(const unsigned char* left, const unsigned char* right, 
  * untouched targets keep their content), the last 10 / 20 columns are cleared, pixels without disparity go to the void
  * channel (the last of n_seg), then both maps are mirrored.  left/right: H x W pixels of `dtype`, pixel stride ld_img;
  * seg: f32 one-hot, pixel stride ld_seg; disp: dense f32.  workspace: sdhip_flip_sample_workspace_bytes(H, W, n_seg). */
+/* augment_DoubleLeftImg of RandomCrop (util/utilTorchDataLoader.py:469-474), in place on ONE prepared sample: left is
+ * mirrored, right becomes the mirrored left, the one-hot map is mirrored, the disparity is 0.0001 everywhere. */
+int sdhip_double_left_sample(void* left, void* right, int ld_img, float* seg, int ld_seg, int n_seg, float* disp, int H, int W,
+                             int dtype, void* stream);
 long sdhip_flip_sample_workspace_bytes(int H, int W, int n_seg);
 int sdhip_flip_sample(void* left, void* right, int ld_img, float* seg, int ld_seg, int n_seg, float* disp, int H, int W,
                       void* workspace, long workspace_bytes, int dtype, void* stream);

@@ -86,3 +86,17 @@ def flip_sample(left, right, seg, disp):
     s_new[:, :, -1] = mask
     s_new[:, :, :-1] *= (1 - mask[:, :, None])
     return new_left, new_right, np.ascontiguousarray(s_new[:, ::-1, :].transpose(2, 0, 1)), np.ascontiguousarray(d_new[None, :, ::-1])
+
+
+def slice_and_switch(left, right, seg, disp, roll):
+    """`sliceandSwitch` of RandomCrop (util/utilTorchDataLoader.py:455-467) on CHW outputs: rows [roll:] first, then [:roll]."""
+    if roll <= 0:
+        return left, right, seg, disp
+    sw = lambda a: np.ascontiguousarray(np.concatenate((a[:, roll:], a[:, :roll]), axis=1))
+    return sw(left), sw(right), sw(seg), sw(disp)
+
+
+def double_left(left, right, seg, disp):
+    """`augment_DoubleLeftImg` (util/utilTorchDataLoader.py:469-474) on CHW outputs."""
+    fl = np.ascontiguousarray(left[:, :, ::-1])
+    return fl, fl.copy(), np.ascontiguousarray(seg[:, :, ::-1]), (np.zeros_like(disp) + 0.0001).astype(disp.dtype)

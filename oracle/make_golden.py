@@ -438,11 +438,19 @@ def gen_data():
              ("garden_tanh", "garden", 9, 12, "tanh", (16, 32), True, ((0., 0., 0.), (1., 1., 1.))),
              ("city_linear", "cityscapes", 19, 192, "linear", (16, 24), True, ((0., 0., 0.), (1., 1., 1.))),
              ("city_flip", "cityscapes", 19, 192, "linear", (16, 32), True, ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))),
-             ("city_flip_whole", "cityscapes", 19, 192, "linear", (24, 40), True, ((0., 0., 0.), (1., 1., 1.)))]
+             ("city_flip_whole", "cityscapes", 19, 192, "linear", (24, 40), True, ((0., 0., 0.), (1., 1., 1.))),
+             # appended (the generator's draws for the cases above are unchanged): the numpy-only augmentations of RandomCrop
+             ("roses_slice", "roses", 2, 192, "linear", (16, 24), True, ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))),
+             ("garden_double", "garden", 9, 12, "tanh", (16, 32), True, ((0., 0., 0.), (1., 1., 1.))),
+             ("city_slice_double_down", "cityscapes", 19, 192, "linear", (16, 24), True, ((0., 0., 0.), (1., 1., 1.))),
+             ("kitti_band", "kitti", 19, 192, "linear", (8, 24), True, ((0., 0., 0.), (1., 1., 1.)))]
+    OPTS = {"roses_slice": dict(slice=True), "garden_double": dict(double=True),
+            "city_slice_double_down": dict(slice=True, double=True, down=True), "kitti_band": dict(band=True)}
     if not hasattr(np, "int"):
         np.int = int          # RandomCrop's flip uses the alias numpy removed in 1.24 (util/utilTorchDataLoader.py:485)
     for name, ds, n_labels, max_d, act, crop, little, norm in cases:
         flip = name.startswith("city_flip")
+        opt = OPTS.get(name, {})
         left = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         right = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         if ds == "roses":
@@ -470,22 +478,34 @@ def gen_data():
             dpath = p("d.png")
             arrays[name + ".depth_u16"] = d16
         normalize = np.array(norm, dtype=np.float32)
-        tf = DL.RandomCrop(list(crop), datasetName=ds, is_down=False, sliceandSwitch=False, augment_DoubleLeftImg=False,
-                           focusPerson=False, resizeImg=False, flipHorizontal=flip)
+        tf = DL.RandomCrop(list(crop), datasetName=ds, is_down=bool(opt.get("down")), sliceandSwitch=bool(opt.get("slice")),
+                           augment_DoubleLeftImg=bool(opt.get("double")), focusPerson=False, resizeImg=False, flipHorizontal=flip)
         dset = DL.CustomDataset([(p("l.png"), p("r.png"))], [(dpath, p("s.png"), p("i.png"))], n_labels, max_d, ds, normalize,
                                 output_activation=act, transform=tf, to_tensor=DL.ToTensor())
         seed = 123
+        from pmt_learning_for_semantic_segmentation_and_disparity_amd import data as PD    # host-side draw helpers only (no GPU call)
         if flip:      # a seed whose draws (crop offsets, then the 50 % flip decision) end in "flip"
-            from pmt_learning_for_semantic_segmentation_and_disparity_amd import data as PD    # host-side draw helpers only (no GPU call)
             for seed in range(123, 200):
                 torch.manual_seed(seed)
                 PD.draw_crop(H, W, list(crop), ds)
                 if PD.draw_flip(ds, True):
                     break
+        if opt.get("double") or opt.get("band"):
+            # a seed whose draws end in the 10 % "double left" decision / in kitti's 80 % lower-band crop
+            for seed in range(123, 400):
+                torch.manual_seed(seed)
+                top = PD.draw_crop(H, W, list(crop), ds, is_down=bool(opt.get("down")))[0]
+                PD.draw_slice_and_switch(H, crop[0], bool(opt.get("slice")))
+                if opt.get("double") and PD.draw_double_left(True):
+                    break
+                if opt.get("band") and top >= 1:
+                    break
         torch.manual_seed(seed)
         s = dset[0]
         arrays.update(flat(name, dict(left_u8=left, right_u8=right, seg_u8=seg, n_labels=np.int64(n_labels), max_d=np.float64(max_d),
                                       crop=np.array(crop, dtype=np.int64), normalize=normalize, seed=np.int64(seed), flip=np.int64(flip),
+                                      opt_slice=np.int64(bool(opt.get("slice"))), opt_double=np.int64(bool(opt.get("double"))),
+                                      opt_down=np.int64(bool(opt.get("down"))),
                                       left=s["left"].numpy(), right=s["right"].numpy(), seg=s["seg"].numpy().astype(np.float32),
                                       disp=s["disp"].numpy().astype(np.float32))))
         arrays[name + ".dataset"] = np.array(ds)

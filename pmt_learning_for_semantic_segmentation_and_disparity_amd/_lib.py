@@ -84,7 +84,8 @@ SIGNATURES = {
     "sdhip_bn_bwd_apply": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _l, _i, _i, _i, _i, _p],
     "sdhip_affine_act_bn": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _d, _f, _f, _i, _i, _p],
     "sdhip_step_metrics": [_p, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _l, _i, _f, _i, _i, _p],
-    "sdhip_prepare_sample": [_p, _p, _l, _i, _p, _l, _i, _i, _i, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p, _p,
+    "sdhip_double_left_sample": [_p, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p],
+    "sdhip_prepare_sample": [_p, _p, _l, _i, _p, _l, _i, _i, _i, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p, _p,
                              _p, _p, _i, _p, _i, _i, _p, _i, _p],
     "sdhip_flip_sample": [_p, _p, _i, _p, _i, _i, _p, _i, _i, _p, _l, _i, _p],
     "sdhip_bn_bwd_apply_fin": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _l, _i, _i, _d, _i, _i, _p],

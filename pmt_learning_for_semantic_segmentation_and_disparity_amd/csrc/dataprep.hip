@@ -17,7 +17,7 @@ struct PrepArgs {
   const unsigned char* seg; long seg_pitch; int seg_cs; int seg_channel; int seg_mode; int seg_threshold;
   const unsigned char* lut;
   const unsigned char* depth; long depth_pitch; int depth_mode; int depth_flip;
-  int H, W, top, left0, oh, ow;
+  int H, W, top, left0, oh, ow, roll;
   float fb, max_d; int activation;
   double mean[3], stdv[3];
   void* out_left; void* out_right; int ld_img;
@@ -30,7 +30,11 @@ __global__ __launch_bounds__(256) void prepare_sample_kernel(const PrepArgs a) {
   const long n = (long)a.oh * a.ow;
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < n; p += (long)gridDim.x * 256) {
     const int oy = (int)(p / a.ow), ox = (int)(p - (long)oy * a.ow);
-    const int y = a.top + oy, x = a.left0 + ox;
+    // sliceandSwitch (RandomCrop, util/utilTorchDataLoader.py:455-467): the cropped maps are cut at row `roll` and the two
+    // pieces exchanged — output row oy is crop row (oy + roll) mod oh
+    int cy = oy + a.roll;
+    if (cy >= a.oh) cy -= a.oh;
+    const int y = a.top + cy, x = a.left0 + ox;
     if (a.left) {
       // ((x / 255.0 - mean) / std).astype(float32): uint8 / python float is float64 in numpy, so is the rest
       const unsigned char* lp = a.left + y * a.img_pitch + (long)x * a.img_cs;
@@ -80,13 +84,14 @@ extern "C" int sdhip_prepare_sample(const unsigned char* left, const unsigned ch
                                     const unsigned char* seg, long seg_pitch, int seg_cs, int seg_channel, int seg_mode,
                                     int seg_threshold, const unsigned char* lut, const void* depth, long depth_pitch,
                                     int depth_mode, int depth_big_endian, int H, int W, int crop_top, int crop_left,
-                                    int out_h, int out_w, float fb, float max_d, int activation, const float* mean,
+                                    int out_h, int out_w, int row_roll, float fb, float max_d, int activation, const float* mean,
                                     const float* stdv, void* out_left, void* out_right, int ld_img, float* out_seg,
                                     int ld_seg, int n_seg, float* out_disp, int dtype, void* stream) {
   SDHIP_CHECK_ARG(H > 0 && W > 0 && out_h > 0 && out_w > 0, "prepare_sample: empty image");
   SDHIP_CHECK_ARG(crop_top >= 0 && crop_left >= 0 && crop_top + out_h <= H && crop_left + out_w <= W,
                   "prepare_sample: crop %dx%d at (%d,%d) leaves the %dx%d image", out_h, out_w, crop_top, crop_left, H, W);
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "prepare_sample: unknown dtype %d", dtype);
+  SDHIP_CHECK_ARG(row_roll >= 0 && row_roll < out_h, "prepare_sample: row_roll %d outside [0, %d)", row_roll, out_h);
   SDHIP_CHECK_ARG(left || seg || depth, "prepare_sample: nothing to do");
   if (left) SDHIP_CHECK_ARG(right && out_left && out_right && mean && stdv && img_cs >= 3 && img_pitch >= (long)W * img_cs && ld_img >= 3,
                             "prepare_sample: image arguments (cs=%d pitch=%ld ld=%d)", img_cs, img_pitch, ld_img);
@@ -109,7 +114,7 @@ extern "C" int sdhip_prepare_sample(const unsigned char* left, const unsigned ch
   a.seg = seg; a.seg_pitch = seg_pitch; a.seg_cs = seg_cs; a.seg_channel = seg_channel; a.seg_mode = seg_mode; a.seg_threshold = seg_threshold;
   a.lut = lut;
   a.depth = (const unsigned char*)depth; a.depth_pitch = depth_pitch; a.depth_mode = depth_mode; a.depth_flip = depth_big_endian;   // the GPU is little-endian
-  a.H = H; a.W = W; a.top = crop_top; a.left0 = crop_left; a.oh = out_h; a.ow = out_w;
+  a.H = H; a.W = W; a.top = crop_top; a.left0 = crop_left; a.oh = out_h; a.ow = out_w; a.roll = row_roll;
   a.fb = fb; a.max_d = max_d; a.activation = activation;
   for (int c = 0; c < 3; ++c) { a.mean[c] = left ? (double)mean[c] : 0.0; a.stdv[c] = left ? (double)stdv[c] : 1.0; }
   a.out_left = out_left; a.out_right = out_right; a.ld_img = ld_img;
@@ -224,6 +229,54 @@ extern "C" int sdhip_flip_sample(void* left, void* right, int ld_img, float* seg
   else
     hipLaunchKernelGGL(flip_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)left, (bf16_t*)right, ld_img, disp, seg, ld_seg,
                        n_seg, (const float*)dtmp, (const float*)stmp, H, W);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
+
+// ---- augment_DoubleLeftImg (RandomCrop, util/utilTorchDataLoader.py:469-474): with probability 0.1 a sample becomes a
+// zero-disparity pair — left mirrored, right = the mirrored left, disparity 0.0001 everywhere, one-hot map mirrored.
+// In place on one prepared batch slot; a thread owns the pixel pair (x, W-1-x) of a row, so the mirror needs no scratch.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void double_left_kernel(T* __restrict__ left, T* __restrict__ right, int ld_img, float* __restrict__ seg,
+                                                          int ld_seg, int n_seg, float* __restrict__ disp, int H, int W) {
+  const int half = (W + 1) / 2;
+  const long n = (long)H * half;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % half);
+    const long r = i / half;
+    const long pa = r * W + x, pb = r * W + (W - 1 - x);
+    if (left) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const T a = left[pa * ld_img + c], b = left[pb * ld_img + c];
+        left[pa * ld_img + c] = b; left[pb * ld_img + c] = a;
+        right[pa * ld_img + c] = b; right[pb * ld_img + c] = a;
+      }
+    }
+    if (seg) {
+      for (int c = 0; c < n_seg; ++c) {
+        const float a = seg[pa * ld_seg + c], b = seg[pb * ld_seg + c];
+        seg[pa * ld_seg + c] = b; seg[pb * ld_seg + c] = a;
+      }
+    }
+    if (disp) { disp[pa] = 0.0001f; disp[pb] = 0.0001f; }      // np.zeros_like(disp) + 0.0001 in float32
+  }
+}
+}  // namespace
+
+extern "C" int sdhip_double_left_sample(void* left, void* right, int ld_img, float* seg, int ld_seg, int n_seg, float* disp,
+                                        int H, int W, int dtype, void* stream) {
+  SDHIP_CHECK_ARG(H > 0 && W > 0 && (left || seg || disp), "double_left_sample: bad arguments");
+  SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "double_left_sample: unknown dtype %d", dtype);
+  if (left) SDHIP_CHECK_ARG(right && ld_img >= 3, "double_left_sample: image arguments");
+  if (seg) SDHIP_CHECK_ARG(n_seg >= 1 && ld_seg >= n_seg, "double_left_sample: segmentation arguments");
+  const long n = (long)H * ((W + 1) / 2);
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == SDHIP_F32) hipLaunchKernelGGL(double_left_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)left, (float*)right, ld_img, seg, ld_seg, n_seg, disp, H, W);
+  else hipLaunchKernelGGL(double_left_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)left, (bf16_t*)right, ld_img, seg, ld_seg, n_seg, disp, H, W);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }

@@ -6,9 +6,13 @@ unpack the PNG containers (PIL), read the PFM header, draw the crop offsets from
 reference's order — and hands the raw bytes to `sdhip_prepare_sample`, which writes one slot of the batch tensors
 directly in the layout the network consumes (channels-last, optionally bf16).
 
-Not reproduced (documented in DESIGN.md): the `cv2.resize` scale augmentation (:411-433), `cropPerson` (:528+),
-the cityscapes flip-with-disparity-shift (:471-500) and the PIL colour jitter (:232-244) — cv2 / skimage are not in this
-image, so their arithmetic cannot be pinned here.
+Augmentations of RandomCrop that are plain numpy / torch-RNG logic upstream run on the device, bit-exact against samples
+the reference's own loader produced: crop (random, `is_down`, kitti's lower band), the cityscapes flip-with-disparity-shift
+(:476-499), `sliceandSwitch` (:455-467) and `augment_DoubleLeftImg` (:469-474); the draw_* helpers consume torch's CPU
+generator in the reference's order.  Not reproduced, because the libraries that define their arithmetic are not in this
+image and their results can therefore not be pinned: the `cv2.resize` scale augmentation (:411-433, cv2), `cropPerson`
+(:528+, skimage.measure.label) and the colour jitter (:232-244,276-300: torchvision.transforms.functional on PIL images +
+PIL GaussianBlur).
 """
 import ctypes
 import re
@@ -84,6 +88,22 @@ def draw_crop(h, w, output_size, dataset_name="roses", is_down=False):
     return top, left, new_h, new_w
 
 
+def draw_slice_and_switch(full_rows, out_rows, enabled=True):
+    """`sliceandSwitch` (util/utilTorchDataLoader.py:455-467): one `randint(2, 6)` after the crop offsets; the cut row is
+    int(ROWS OF THE UNCROPPED IMAGE / divisor) — `w, h, c = images[0].shape` is read before the crop loop — and it is applied
+    to the cropped maps: a cut at or beyond their last row leaves them unchanged.  Returns the row_roll of prepare_into."""
+    if not enabled:
+        return 0
+    divisor = float(torch.randint(2, 6, (1,)))
+    cut = int(full_rows / divisor)
+    return cut if cut < out_rows else 0
+
+
+def draw_double_left(enabled=True):
+    """`augment_DoubleLeftImg and multinomial([0.9, 0.1])` (:469): drawn only when the option is on, after sliceandSwitch."""
+    return bool(enabled and torch.multinomial(torch.tensor([0.9, 0.1]), 1).item())
+
+
 def draw_flip(dataset_name, flip_horizontal=True):
     """The flip decision as RandomCrop draws it (util/utilTorchDataLoader.py:476): `flipHorizontal and multinomial([.5,.5])
     and datasetName == 'cityscapes'` — the draw happens whenever the option is on (short-circuit order), after the crop
@@ -140,10 +160,11 @@ class SamplePreparer:
         self._keep.append(t)
         return t
 
-    def prepare_into(self, batch, b, left, right, seg, depth, crop=None):
+    def prepare_into(self, batch, b, left, right, seg, depth, crop=None, row_roll=0):
         """left/right: uint8 (H,W,>=3) arrays; seg: uint8 (H,W[,C]); depth: the raw bytes of a .pfm file (roses/garden)
-        or a uint16 (H,W) array (kitti/cityscapes); crop = (top, left, h, w) or None for the whole image.
-        Writes slot `b` of batch = (left, right, seg, disp) as returned by alloc_batch.  Asynchronous."""
+        or a uint16 (H,W) array (kitti/cityscapes); crop = (top, left, h, w) or None for the whole image; row_roll: the
+        sliceandSwitch cut (draw_slice_and_switch).  Writes slot `b` of batch = (left, right, seg, disp) as returned by
+        alloc_batch.  Asynchronous."""
         bl, br, bs, bd = batch
         H, W = left.shape[:2]
         top, lft, oh, ow = crop if crop is not None else (0, 0, H, W)
@@ -180,7 +201,7 @@ class SamplePreparer:
         if bl.stride(1) != 1 or bs.stride(1) != 1 or not od.is_contiguous():
             raise _lib.SdhipError("batch tensors must be channels-last (use alloc_batch)")
         call("sdhip_prepare_sample", ptr(dl), ptr(dr), W * cs, cs, ptr(ds), W * seg3.shape[2], seg3.shape[2], seg_channel,
-             self.seg_mode, 128, ptr(self.lut), ptr(dd), pitch, self.depth_mode, big, H, W, top, lft, oh, ow, self.fb, self.max_d,
+             self.seg_mode, 128, ptr(self.lut), ptr(dd), pitch, self.depth_mode, big, H, W, top, lft, oh, ow, int(row_roll), self.fb, self.max_d,
              self.activation, ctypes.cast(self.mean, ctypes.c_void_p), ctypes.cast(self.std, ctypes.c_void_p), ptr(ol), ptr(orr),
              ld_img, ptr(os_), ld_seg, self.n_seg, ptr(od), _lib.dtype_code(bl), stream_ptr())
 
@@ -195,6 +216,12 @@ class SamplePreparer:
             ws = self._flip_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         call("sdhip_flip_sample", ptr(bl[b]), ptr(br[b]), bl.stride(3), ptr(bs[b]), bs.stride(3), self.n_seg, ptr(bd[b]), H, W,
              ptr(ws), ws.numel(), _lib.dtype_code(bl), stream_ptr())
+
+    def double_left_slot(self, batch, b):
+        """augment_DoubleLeftImg on slot `b`, in place (call it after prepare_into when draw_double_left said so)."""
+        bl, br, bs, bd = batch
+        call("sdhip_double_left_sample", ptr(bl[b]), ptr(br[b]), bl.stride(3), ptr(bs[b]), bs.stride(3), self.n_seg, ptr(bd[b]),
+             bl.shape[2], bl.shape[3], _lib.dtype_code(bl), stream_ptr())
 
     def release(self):
         """Drop the staged uint8 inputs (call after the batch has been consumed or the stream synchronised)."""

@@ -11,7 +11,8 @@ import torch
 from oracle import data_ref as DR
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "data.npz")
-CASES = ("roses_linear", "roses_crop", "roses_sigmoid_be", "garden_tanh", "city_linear", "city_flip", "city_flip_whole")
+CASES = ("roses_linear", "roses_crop", "roses_sigmoid_be", "garden_tanh", "city_linear", "city_flip", "city_flip_whole",
+         "roses_slice", "garden_double", "city_slice_double_down", "kitti_band")
 
 
 def _case(gold, name):
@@ -20,27 +21,40 @@ def _case(gold, name):
     depth = g("depth_file").tobytes() if ds in ("roses", "garden") else g("depth_u16")
     return dict(left=g("left_u8"), right=g("right_u8"), seg=g("seg_u8"), depth=depth, dataset=ds, n_labels=int(g("n_labels")),
                 max_d=float(g("max_d")), activation=str(g("activation")), normalize=g("normalize"), crop=tuple(int(v) for v in g("crop")),
-                seed=int(g("seed")))
+                seed=int(g("seed")), flip=bool(int(g("flip"))), opt_slice=bool(int(g("opt_slice"))), opt_double=bool(int(g("opt_double"))),
+                opt_down=bool(int(g("opt_down"))))
+
+
+def _draws(c):
+    """(crop, row_roll, double_left, flip): RandomCrop's random decisions from the fixture's seed, drawn in the reference's
+    order (util/utilTorchDataLoader.py:435-476) by the product's host-side helpers."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import data as PD
+    torch.manual_seed(c["seed"])
+    H, W = c["left"].shape[:2]
+    crop = PD.draw_crop(H, W, list(c["crop"]), c["dataset"], is_down=c["opt_down"])
+    roll = PD.draw_slice_and_switch(H, crop[2], c["opt_slice"])
+    dbl = PD.draw_double_left(c["opt_double"])
+    flip = PD.draw_flip(c["dataset"], c["flip"])
+    return crop, roll, dbl, flip
 
 
 def _crop(c):
-    from pmt_learning_for_semantic_segmentation_and_disparity_amd.data import draw_crop
-    torch.manual_seed(c["seed"])
-    H, W = c["left"].shape[:2]
-    return draw_crop(H, W, list(c["crop"]), c["dataset"])
+    return _draws(c)[0]
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_and_crop_draws_match_reference_loader(name):
     gold = np.load(GOLD)
     c = _case(gold, name)
-    crop = _crop(c)
+    crop, roll, dbl, flip = _draws(c)
     lut = gold["cityscapes.id2trainId"]
     out = DR.prepare_sample(c["left"], c["right"], c["seg"], c["depth"], c["dataset"], c["n_labels"], c["max_d"], c["activation"],
                             c["normalize"], crop, id2train=lut)
-    if name.startswith("city_flip"):          # RandomCrop(flipHorizontal=True): the draw after the crop offsets says "flip"
-        from pmt_learning_for_semantic_segmentation_and_disparity_amd.data import draw_flip
-        assert int(gold[name + ".flip"]) == 1 and draw_flip(c["dataset"], True)
+    out = DR.slice_and_switch(*out, roll)
+    assert flip == name.startswith("city_flip") and dbl == ("double" in name) and (roll > 0) == ("slice" in name)
+    if dbl:
+        out = DR.double_left(*out)
+    if flip:                                   # RandomCrop(flipHorizontal=True): the draw after the crop offsets says "flip"
         out = DR.flip_sample(*out)
     for k, v in zip(("left", "right", "seg", "disp"), out):
         np.testing.assert_array_equal(v, gold["%s.%s" % (name, k)], err_msg=k)
@@ -84,13 +98,40 @@ def test_crop_draw_consumes_generator_like_reference():
     assert draw_crop(24, 40, (16, 24), is_down=True) == (8, 8, 16, 24)
 
 
-def _gpu_prepare(c, crop, dtype, slot=1, B=3, flip=False):
+def test_kitti_lower_band_and_slice_rules():
+    """kitti: with probability 0.8 the crop comes from the lowest new_h + 100 rows (util/utilTorchDataLoader.py:442-445); the
+    sliceandSwitch cut is computed from the UNCROPPED row count and is a no-op when it falls beyond the crop."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import data as PD
+    tops = []
+    for seed in range(40):
+        torch.manual_seed(seed)
+        hit = bool(torch.multinomial(torch.tensor([0.2, 0.8]), 1).item())
+        torch.manual_seed(seed)
+        top = PD.draw_crop(400, 600, (50, 100), "kitti")[0]
+        assert (top >= 250) if hit else (0 <= top <= 350)
+        tops.append((hit, top))
+        torch.manual_seed(seed)
+        assert 0 <= PD.draw_crop(400, 600, (50, 100), "roses")[0] <= 350
+    assert any(h for h, _ in tops) and any(not h for h, _ in tops)
+    for seed in range(10):
+        torch.manual_seed(seed)
+        div = float(torch.randint(2, 6, (1,)))
+        torch.manual_seed(seed)
+        assert PD.draw_slice_and_switch(400, 50, True) == (int(400 / div) if int(400 / div) < 50 else 0) == 0
+        torch.manual_seed(seed)
+        assert PD.draw_slice_and_switch(40, 32, True) == int(40 / div)
+    assert PD.draw_slice_and_switch(40, 32, False) == 0 and PD.draw_double_left(False) is False
+
+
+def _gpu_prepare(c, crop, dtype, slot=1, B=3, flip=False, roll=0, dbl=False):
     from pmt_learning_for_semantic_segmentation_and_disparity_amd.data import SamplePreparer
     sp = SamplePreparer(c["dataset"], c["n_labels"], c["max_d"], c["activation"], c["normalize"], dtype=dtype, device="cuda:0")
     batch = sp.alloc_batch(B, crop[2], crop[3])
     for t in batch:
         t.fill_(-7.0)
-    sp.prepare_into(batch, slot, c["left"], c["right"], c["seg"], c["depth"], crop)
+    sp.prepare_into(batch, slot, c["left"], c["right"], c["seg"], c["depth"], crop, row_roll=roll)
+    if dbl:
+        sp.double_left_slot(batch, slot)
     if flip:
         sp.flip_slot(batch, slot)
     torch.cuda.synchronize()
@@ -103,12 +144,12 @@ def _gpu_prepare(c, crop, dtype, slot=1, B=3, flip=False):
 def test_hip_prepare_matches_reference_loader(name):
     gold = np.load(GOLD)
     c = _case(gold, name)
-    crop = _crop(c)
-    batch = _gpu_prepare(c, crop, torch.float32, flip=name.startswith("city_flip"))
+    crop, roll, dbl, flip = _draws(c)
+    batch = _gpu_prepare(c, crop, torch.float32, flip=flip, roll=roll, dbl=dbl)
     for k, t in zip(("left", "right", "seg", "disp"), batch):
         np.testing.assert_array_equal(t[1].cpu().numpy(), gold["%s.%s" % (name, k)], err_msg=k)     # bit-exact (NaN-free outputs)
         assert float(t[0].min()) == -7.0 and float(t[2].max()) == -7.0                               # other slots untouched
-    b16 = _gpu_prepare(c, crop, torch.bfloat16, flip=name.startswith("city_flip"))
+    b16 = _gpu_prepare(c, crop, torch.bfloat16, flip=flip, roll=roll, dbl=dbl)
     for k, t in zip(("left", "right"), b16[:2]):
         want = torch.from_numpy(gold["%s.%s" % (name, k)]).to(torch.bfloat16)
         assert torch.equal(t[1].cpu(), want), k

@@ -32,13 +32,18 @@ def flatten_parameters(model):
 
 class TrainStep:
     def __init__(self, model, dtype=torch.bfloat16, lr=0.0015, betas=(0.9, 0.999), eps=1e-7, use_lovasz=True,
-                 use_graph=True, world_size=1, process_group=None, use_side_stream=None, loss_fn=None, metrics=None):
+                 use_graph=True, world_size=1, process_group=None, use_side_stream=None, loss_fn=None, metrics=None, accumulate=1):
         self.model, self.dtype, self.use_lovasz = model, dtype, use_lovasz
         # metrics.StepMetrics (or None): scored inside the step on the second segmentation head and the disparity, as the
         # reference's lossSeg_fn(seg2) / lossDisp_fn calls do (torch_implementation.py:293,304) — one extra launch, graph-safe
         self.metrics = metrics
         self.loss_fn = loss_fn      # (outputs, seg, disp) -> scalar; default: the joint seg+disp loss of the reference step
         self.lr, self.betas, self.eps = lr, betas, eps
+        # gradient accumulation (`-acmt_grad K`, torch_implementation.py:335,362,390-397): K calls form one optimizer step — the
+        # gradients of K micro-batches add up in the flat buffer, the K-th call all-reduces, steps with their mean and clears
+        self.accumulate = max(1, int(accumulate))
+        self._micro = 0
+        self.graphs = {}            # (first, last) call of an accumulation cycle -> (hipGraph, its loss tensor)
         self.world_size, self.pg = world_size, process_group
         parallel.configure(process_group, world_size)     # sync-BN statistics exchange + gradient all-reduce
         self.flat_p, self.flat_g = flatten_parameters(model)
@@ -99,10 +104,12 @@ class TrainStep:
             call("sdhip_conv_pack_batch", ptr(self.pack_desc), self.pack_desc.shape[0],
                  _lib.BF16 if self.dtype == torch.bfloat16 else _lib.F32, stream_ptr())
 
-    def forward_backward(self, left, right, seg, disp):
+    def forward_backward(self, left, right, seg, disp, first=True):
+        """first: this call opens an accumulation cycle — the flat gradient buffer is cleared; later calls of the cycle add."""
         ops.set_step_context(self.ctx)
         self.ctx.begin_step()       # one memset clears every zero-initialised workspace of the step
-        self.flat_g.zero_()
+        if first:
+            self.flat_g.zero_()
         self.pack_all()             # one launch packs every weight (forward and data-grad orientation)
         outs = self.model(left.to(self.dtype), right.to(self.dtype))
         if self.loss_fn is not None:
@@ -120,13 +127,26 @@ class TrainStep:
 
     def optimizer_step(self):
         call("sdhip_adam_step", ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.beta_pow),
-             self.flat_p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, 0.0, 1.0 / self.world_size, stream_ptr())
+             self.flat_p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, 0.0, 1.0 / (self.world_size * self.accumulate),
+             stream_ptr())
         ops.invalidate_packed_weights()
 
-    def _eager(self, left, right, seg, disp):
-        loss = self.forward_backward(left, right, seg, disp)
-        self.all_reduce()
-        self.optimizer_step()
+    def _phase(self):
+        """(first, last) of the call about to run within its accumulation cycle; advances the cycle counter."""
+        first = self._micro == 0
+        self._micro += 1
+        last = self._micro >= self.accumulate
+        if last:
+            self._micro = 0
+        return first, last
+
+    def _eager(self, left, right, seg, disp, phase=None):
+        """One (micro-)step.  phase = (first, last) of the accumulation cycle (None: decided by the call counter)."""
+        first, last = phase if phase is not None else self._phase()
+        loss = self.forward_backward(left, right, seg, disp, first)
+        if last:
+            self.all_reduce()
+            self.optimizer_step()
         if self.ctx.arena is None:
             self._arm()
         elif self.nbt_tensors:
@@ -134,7 +154,7 @@ class TrainStep:
         # next step draws new dropout masks.  A device-side add AFTER the backward pass (which regenerates this step's
         # masks from the same seed): captured into the graph, so every replay advances it too.
         self.ctx.seed.add_(1)
-        if not torch.cuda.is_current_stream_capturing():
+        if last and not torch.cuda.is_current_stream_capturing():
             self.steps_done += 1
         return loss
 
@@ -147,7 +167,7 @@ class TrainStep:
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
-            for _ in range(warmup):
+            for _ in range(warmup * self.accumulate - self._micro):      # whole accumulation cycles: the capture starts at a cycle boundary
                 self._eager(*self.static)
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
@@ -158,7 +178,6 @@ class TrainStep:
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        graph = torch.cuda.CUDAGraph(keep_graph=self.debug_graph)    # kept: _lib.graph_node_counts (node inventory tests)
         # data parallel: the RCCL watchdog thread polls events while we capture; thread-local capture errors keep its
         # (legal) calls from invalidating the capture of this thread
         mode = "thread_local" if self.world_size > 1 else "global"
@@ -169,22 +188,31 @@ class TrainStep:
         gc_was_on = gc.isenabled()
         gc.disable()
         self._gen_state = self._torch_generator_state()    # restored exactly should the capture fail (_abandon_capture)
+        graphs = {}
+        K = self.accumulate
+        phases = [(True, True)] if K == 1 else ([(True, False), (False, True)] if K == 2 else [(True, False), (False, False), (False, True)])
         try:
-            with torch.cuda.stream(cap):
-                graph.capture_begin(capture_error_mode=mode)
-                try:
-                    self.loss = self._eager(*self.static)
-                    if self._capture_fault is not None:
-                        self._capture_fault()
-                    graph.capture_end()
-                except BaseException:
-                    self._close_broken_capture(graph, cap)
-                    raise
+            # one graph per kind of call of an accumulation cycle: the opening one clears the gradient buffer, the closing one
+            # holds the all-reduce and Adam (accumulate = 1: one graph that does both)
+            for ph in phases:
+                graph = torch.cuda.CUDAGraph(keep_graph=self.debug_graph)    # kept: _lib.graph_node_counts (node inventory tests)
+                with torch.cuda.stream(cap):
+                    graph.capture_begin(capture_error_mode=mode)
+                    try:
+                        loss = self._eager(*self.static, phase=ph)
+                        if self._capture_fault is not None:
+                            self._capture_fault()
+                        graph.capture_end()
+                    except BaseException:
+                        self._close_broken_capture(graph, cap)
+                        raise
+                graphs[ph] = (graph, loss)
         finally:
             if gc_was_on:
                 gc.enable()
         torch.cuda.current_stream().wait_stream(cap)
-        self.graph = graph
+        self.graphs = graphs
+        self.graph, self.loss = graphs[phases[-1]]      # the closing call's graph (accumulate = 1: the only one)
         return self
 
     def _close_broken_capture(self, graph, cap):
@@ -217,7 +245,7 @@ class TrainStep:
         """A capture that raised recorded launches but executed none: device state (parameters, moments, running
         statistics, dropout seed) is that of the last eager warm-up step.  Only host-side bookkeeping of the half-recorded
         step has to be reset before eager steps continue."""
-        self.graph, self.use_graph, self.loss = None, False, None
+        self.graph, self.graphs, self.use_graph, self.loss = None, {}, False, None
         torch.cuda.synchronize()               # raises if the process could not be brought back: nothing can run then
         # capture_begin put torch's default CUDA generator into capture mode and only a completed capture_end takes it out
         # again ("Offset increment outside graph capture" on the next torch.randn(device='cuda')): give the generator a
@@ -255,9 +283,12 @@ class TrainStep:
         for dst, src in zip(self.static, (left, right, seg, disp)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
-        self.graph.replay()
-        self.steps_done += 1
-        return self.loss
+        ph = self._phase()
+        graph, loss = self.graphs[ph]
+        graph.replay()
+        if ph[1]:
+            self.steps_done += 1
+        return loss
 
 
 def _backend_of(pg):

@@ -318,3 +318,62 @@ def test_pack_table_holds_only_the_steps_own_weights():
     assert not (set(src.tolist()) & foreign)
     del other
     ops.set_step_context(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_gradient_accumulation_matches_reference_rule(graph):
+    """`-acmt_grad K` (torch_implementation.py:335,362,390-397): the loss of each of K consecutive batches is divided by K and
+    back-propagated, the optimizer steps once.  TrainStep(accumulate=3): three calls (one per micro-batch) produce the
+    parameters of ONE Adam step on the mean of the three micro-batch gradients — checked against three single steps' own
+    gradients (lr 0 runs on the same weights) fed to torch.optim.Adam, eagerly and with one hipGraph per kind of call
+    (opening / middle / closing call of a cycle)."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep, synthetic_batch
+    batches = [synthetic_batch(2, 256, 256, seed=100 + i) for i in range(3)]
+    # gradient of every micro-batch at the initial weights (eval-mode BatchNorm would hide nothing here: train mode, but the
+    # running statistics do not enter the train-mode forward, so the three gradients are independent of the call order)
+    ref = TrainStep(_model(), dtype=torch.float32, use_graph=False, lr=0.0)
+    gsum = torch.zeros_like(ref.flat_g)
+    for b in batches:
+        ref(*b)
+        gsum += ref.flat_g
+    w0 = ref.flat_p.clone()
+    ops.set_step_context(None)
+    p = w0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=1e-3, betas=(0.9, 0.999), eps=1e-7)
+    p.grad = gsum / 3
+    opt.step()
+    if not graph:
+        ts = TrainStep(_model(), dtype=torch.float32, use_graph=False, lr=1e-3, accumulate=3)
+        assert torch.equal(ts.flat_p, w0)
+        for b in batches:
+            ts(*b)
+        ops.set_step_context(None)
+        assert ts.steps_done == 1
+        d_want, d_got = (p.detach() - w0), (ts.flat_p - w0)
+        assert float(d_want.norm()) > 0
+        # Adam's first step moves every parameter by ~lr * sign(g): compare the update vectors, and the accumulated gradient
+        assert float((d_got - d_want).norm() / d_want.norm()) < 2e-2
+        assert float((ts.flat_g / 3 - gsum / 3).norm() / (gsum / 3).norm()) < 2e-2
+        return
+    # graph mode (one hipGraph per kind of call: opening / middle / closing call of a cycle).  lr 0 keeps the weights at w0, so
+    # the buffer the closing call hands to Adam can be compared directly: the sum of the three micro-batch gradients
+    ts = TrainStep(_model(), dtype=torch.float32, use_graph=True, lr=0.0, accumulate=3)
+    for c in range(2):
+        for b in batches:
+            ts(*b)
+        assert float((ts.flat_g - gsum).norm() / gsum.norm()) < 2e-2, c
+    assert ts.steps_done == 2 + 2                                    # two eager warm-up cycles precede the capture
+    assert set(ts.graphs) == {(True, False), (False, False), (False, True)} and torch.equal(ts.flat_p, w0)
+    ops.set_step_context(None)
+    # ... and with a learning rate the replayed cycles keep stepping
+    ts = TrainStep(_model(), dtype=torch.float32, use_graph=True, lr=1e-4, accumulate=2)
+    seen = []
+    for c in range(3):
+        for b in batches[:2]:
+            ts(*b)
+        seen.append(ts.flat_p.clone())
+    ops.set_step_context(None)
+    assert set(ts.graphs) == {(True, False), (False, True)} and ts.steps_done == 5
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])

@@ -17,6 +17,7 @@
 // into the packed f32 gradient buffer.
 #include "conv_common.h"
 #include "conv_wgrad_fast.h"
+#include "conv_wgrad_half.h"
 #include "conv_thin.h"
 #include <algorithm>
 #include <vector>
@@ -475,6 +476,15 @@ static int wgrad_one(const void* x, const void* dy, float* dw_packed, float* dbi
     f.tpb = a.tpb; f.ntg = a.ntg; f.nq = a.nq;
     if (T == 1 && a.tpb == 1) { f.tpb = 1; f.ntg = 1; }
     f.qb = 0; f.qsh = 0; f.nq_tot = a.nq;
+    // <= 32 channels on both sides, 3x3 (x3), stride 1: 64-byte LDS rows, all depth taps per workgroup (conv_wgrad_half.h)
+    if (Cin <= 32 && Cout <= 32 && kh == 3 && kw == 3 && stride == 1 && dil == 1 && sd == 1 && (kd == 1 || kd == 3) && !in_scale && !dbias &&
+        Wo >= 24 && !sdhip_diag().wgrad_no_half32) {
+      WgfPlan pl;
+      const int rc = kd == 3 ? plan_wg32<3>(f, pl) : plan_wg32<1>(f, pl);
+      if (rc != SDHIP_OK) return rc;
+      if (plan) { *plan = pl; *planned = true; return SDHIP_OK; }
+      return launch_wgf_plan(pl, s);
+    }
     // 1x1 with many input channels (DenseNet bottlenecks / transitions): pack 2 or 4 channel chunks per workgroup
     const bool no_pack = sdhip_diag().wgrad_no_pack;   // diagnostics: A/B against the unpacked kernel
     // Measured (tools/gpu_wgrad1x1_ab.sh): it pays on large maps and wide outputs (192->128 at 16x64x128: 88 -> 52 us,

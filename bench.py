@@ -106,7 +106,7 @@ def kernel_roofline(dtype, B, H, W):
     # HBM bytes per launch of this kernel from the PMC passes committed under profiles/ (FETCH_SIZE doubled as the gfx950
     # note of MI355X_MICROARCH.md prescribes, + WRITE_SIZE; tools/roofline_profile.sh); null when no profile is committed
     traffic, src, busy = None, None, None
-    for name in ("r02_roofline_traffic.json", "r01_roofline_traffic.json"):
+    for name in ("r03_roofline_traffic.json", "r02_roofline_traffic.json", "r01_roofline_traffic.json"):
         tj = os.path.join(ROOT, "profiles", name)
         if dtype == torch.bfloat16 and (B, H, W) == (8, 256, 512) and os.path.exists(tj):
             try:

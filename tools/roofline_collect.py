@@ -1,8 +1,9 @@
-"""Turn gpurun_out/roofline/* (tools/roofline_profile.sh) into the committed profiles/r02_* files."""
+"""Turn gpurun_out/roofline/* (tools/roofline_profile.sh) into the committed profiles/<round tag>_* files."""
 import collections, csv, json, os, re, shutil
 R = "gpurun_out/roofline"
-TAG = "r02"
-os.makedirs("profiles", exist_ok=True)
+TAG = os.environ.get("SDHIP_PROFILE_TAG", "r03")
+PD = os.environ.get("SDHIP_PROFILE_DIR", "gpurun_out/profiles")     # merged back by gpurun; copy into profiles/ to commit
+os.makedirs(PD, exist_ok=True)
 
 
 def kstats(path, out, top=40):
@@ -27,9 +28,9 @@ def short(n):
     return re.sub(r"^void ", "", n).split("(")[0][:80]
 
 
-rows = kstats(R + "/stats/r_kernel_stats.csv", "profiles/%s_roofline_kernel_stats.csv" % TAG)
-kstats(R + "/step/r_kernel_stats.csv", "profiles/%s_bench_graph_kernel_stats.csv" % TAG, 60)
-shutil.copy(R + "/step_summary.txt", "profiles/%s_step_summary.txt" % TAG)
+rows = kstats(R + "/stats/r_kernel_stats.csv", PD + "/%s_roofline_kernel_stats.csv" % TAG)
+kstats(R + "/step/r_kernel_stats.csv", PD + "/%s_bench_graph_kernel_stats.csv" % TAG, 60)
+shutil.copy(R + "/step_summary.txt", PD + "/%s_step_summary.txt" % TAG)
 DOM = "conv_band_kernel" if any("conv_band_kernel" in r["Name"] for r in rows) else "conv_fast_kernel"
 conv = [r for r in rows if DOM in r["Name"]][0]
 avg = lambda acc, pat, name: (lambda v: (sum(v) / len(v), len(v)))([x for k, d in acc.items() if pat in k for x in d.get(name, [])])
@@ -58,7 +59,7 @@ out = {"kernel": conv["Name"][:160], "avg_ns_rocprof": float(conv["AverageNs"]),
        "note": "hbm = fetch_scale*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes, bench.py --roofline-only; fetch_scale 1 for the "
                "64-byte-request pattern of the band kernel (profiles/r02_band_traffic_calibration.txt), 2 for whole-line readers; mfma_busy_frac = "
                "SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles at 2.4 GHz x 1024 SIMDs)"}
-json.dump(out, open("profiles/%s_roofline_traffic.json" % TAG, "w"), indent=1)
+json.dump(out, open(PD + "/%s_roofline_traffic.json" % TAG, "w"), indent=1)
 print(json.dumps(out, indent=1))
 
 # per-kernel-family table of one eager step: duration (kernel trace of the graph run), MFMA busy, HBM bytes
@@ -78,7 +79,7 @@ dur = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(R + "/step/r_kernel_stats.csv")):
     d = dur[short(r["Name"])]
     d[0] += int(r["Calls"]); d[1] += float(r["TotalDurationNs"])
-with open("profiles/%s_step_counters.csv" % TAG, "w") as f:
+with open(PD + "/%s_step_counters.csv" % TAG, "w") as f:
     f.write("kernel,launches (3 eager steps),SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES,hbm_MB (fetch_scale*FETCH+WRITE),"
             "hbm_MB_per_launch,avg_us_per_launch (graph run),GB/s,frac_of_8TB/s,fetch_scale\n")
     fs = lambda k: 1.0 if "conv_band_kernel<5, 64" in k else 2.0      # 64-byte read requests: r02_band_traffic_calibration.txt
@@ -88,4 +89,4 @@ with open("profiles/%s_step_counters.csv" % TAG, "w") as f:
         us = dur[k][1] / dur[k][0] / 1e3 if dur[k][0] else 0.0
         gbs = (mb / n) / us * 1e3 if us else 0.0
         f.write('"%s",%d,%.4g,%.4g,%.1f,%.2f,%.1f,%.0f,%.3f,%.0f\n' % (k, v["n"], v["busy"], v["sq"], mb, mb / n, us, gbs, gbs / 8000.0, fs(k)))
-print(open("profiles/%s_step_counters.csv" % TAG).read()[:3000])
+print(open(PD + "/%s_step_counters.csv" % TAG).read()[:3000])

@@ -22,4 +22,9 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/step_fetch -o r -- python bench.py --steps 1 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --no-secondary > $OUT/step_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/step_write -o r -- python bench.py --steps 1 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --no-secondary > $OUT/step_write.log 2>&1
 python tools/roofline_collect.py
+# the secondary configurations' steps (dsnet = BASELINE config 2 as literally named, PSMNet(192) = config 3)
+for m in dsnet psmnet; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_$m -o r -- python bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > $OUT/step_$m.log 2>&1
+  python tools/trace_summary.py $OUT/step_$m/r_kernel_trace.csv > ${SDHIP_PROFILE_DIR:-gpurun_out/profiles}/${SDHIP_PROFILE_TAG:-r03}_${m}_step_summary.txt
+done
 tail -1 $OUT/stats.log

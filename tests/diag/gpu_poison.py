@@ -58,3 +58,21 @@ for dt in (torch.float32, torch.bfloat16):
         l, r, seg, disp = synthetic_batch(B, H, W, seed=7)
         m = PSMNet(64).cuda().train()
         check("PSMNet(64)", m, (l.to(dt), r.to(dt)), lambda o: ops.mean_l1_loss(o, disp[:, 0]), dt)
+
+# the training step itself (zero arena, queued + grouped weight gradients, fused Adam), eager and captured
+if "step" in (sys.argv[1:] or ["step"]):
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.train import TrainStep
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd.psmnet import PSMNet
+    for name, mk, lf in (("minidsnetExt", lambda: N.minidsnetExt(N.CFG(), labels=2, patch_type='1dcorr').cuda().train(), None),
+                         ("dsnet", lambda: N.dsnet(N.CFG(), labels=2).cuda().train(),
+                          lambda o, seg, disp: ops.train_loss(o[0], o[1], o[2], seg, disp, True)),
+                         ("PSMNet(64)", lambda: PSMNet(64).cuda().train(), lambda o, seg, disp: ops.mean_l1_loss(o, disp[:, 0]))):
+        for graph in (False, True):
+            torch.manual_seed(0)
+            batch = synthetic_batch(2, 256, 256, seed=7)
+            ts = TrainStep(mk(), dtype=torch.bfloat16, use_graph=graph, lr=1e-4, loss_fn=lf)
+            losses = [float(ts(*batch)) for _ in range(3)]
+            ok = all(l == l for l in losses) and bool(torch.isfinite(ts.flat_g).all()) and bool(torch.isfinite(ts.flat_p).all())
+            print("%-14s TrainStep graph=%-5s losses %s  finite gradients / parameters: %s" % (name, graph, ["%.4f" % l for l in losses], ok), flush=True)
+            ops.set_step_context(None)
+            del ts

@@ -246,13 +246,19 @@ __global__ __launch_bounds__(256) void affine_act_bn_kernel(const T* __restrict_
                                                             int C, long npix_g, double count, float eps, float momentum, int act, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
   __shared__ float s_sc[64 * 8], s_sf[64 * 8];
-  __shared__ double s_red[2][8][32];
+  __shared__ double s_red[2][256];
   const int G = gridDim.z, g = blockIdx.z;
   const int ch0 = blockIdx.y * rg.tx * N;
   const int nch = min(rg.tx, rg.units - (int)blockIdx.y * rg.tx) * N;
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  // Replica fold of the workgroup's channels in ONE round trip: the 256 threads are (channel slot cl, replica lane rl) with as
+  // many replica lanes as fit (64 channels: 4 lanes of 8 replicas each), one barrier pair per statistics group.  (The first
+  // form walked the channels 32 at a time — four dependent load / barrier rounds for the 128-channel DenseNet bottlenecks,
+  // most of this kernel's time on the small maps.)
+  const int ncp = nch <= 32 ? 32 : nch <= 64 ? 64 : nch <= 128 ? 128 : 256;
+  const int P = 256 / ncp;
+  const int cl = threadIdx.x & (ncp - 1), rl = threadIdx.x / ncp;
   const bool writer = blockIdx.x == 0 && g == 0 && rmean;   // wave-uniform per workgroup: running statistics of the slice
-  for (int cb = 0; cb < nch; cb += 32) {
+  for (int cb = 0; cb < nch; cb += ncp) {
     const int c = ch0 + cb + cl;
     const bool okc = cb + cl < nch && c < C;
     float rm = 0.f, rv = 0.f;
@@ -261,19 +267,18 @@ __global__ __launch_bounds__(256) void affine_act_bn_kernel(const T* __restrict_
       if (gg != g && !writer) continue;                      // everybody needs its own group; the writer all, in order
       double a1 = 0., a2 = 0.;
       if (okc) {
-        for (int r = rl; r < nrep; r += 8) {
+        for (int r = rl; r < nrep; r += P) {
           const double* Sr = S + (long)r * G * 2 * ldc;
           a1 += Sr[((long)gg * 2 + 0) * ldc + c];
           a2 += Sr[((long)gg * 2 + 1) * ldc + c];
         }
       }
       __syncthreads();
-      s_red[0][rl][cl] = a1; s_red[1][rl][cl] = a2;
+      s_red[0][threadIdx.x] = a1; s_red[1][threadIdx.x] = a2;
       __syncthreads();
       if (rl == 0 && okc) {
         double s1 = 0., s2 = 0.;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { s1 += s_red[0][r][cl]; s2 += s_red[1][r][cl]; }
+        for (int r = 0; r < P; ++r) { s1 += s_red[0][r * ncp + cl]; s2 += s_red[1][r * ncp + cl]; }
         const double mu = s1 / count;
         double var = s2 / count - mu * mu;
         if (var < 0.) var = 0.;
@@ -333,13 +338,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* gy, int 
                                                                double inv_count, int act, const double* __restrict__ dsum, RowGeom rg) {
   constexpr int N = Unit<T, VEC>::N;
   __shared__ float s_a[64 * 8], s_b2[64 * 8];
-  __shared__ float s_red[2][8][32];
+  __shared__ float s_red[2][256];
   const int G = gridDim.z, g = blockIdx.z;
   const int ch0 = blockIdx.y * rg.tx * N;
   const int nch = min(rg.tx, rg.units - (int)blockIdx.y * rg.tx) * N;
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  // replica fold in one round trip (see affine_act_bn_kernel): threads = (channel slot cl, replica lane rl)
+  const int ncp = nch <= 32 ? 32 : nch <= 64 ? 64 : nch <= 128 ? 128 : 256;
+  const int P = 256 / ncp;
+  const int cl = threadIdx.x & (ncp - 1), rl = threadIdx.x / ncp;
   const bool writer = blockIdx.x == 0 && g == 0 && dgamma;     // wave-uniform per workgroup
-  for (int cb = 0; cb < nch; cb += 32) {
+  for (int cb = 0; cb < nch; cb += ncp) {
     const int c = ch0 + cb + cl;
     const bool okc = cb + cl < nch && c < C;
     float dg = 0.f, db = 0.f;
@@ -349,19 +357,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* gy, int 
       if (okc) {
         if (dsum) {   // f64 [nrep][G][2][C] as written by the epilogue of sdhip_conv2d_fwd_bnbwd
           double d0 = 0., d1 = 0.;
-          for (int r = rl; r < nrep; r += 8) { d0 += dsum[(((long)r * G + gg) * 2 + 0) * C + c]; d1 += dsum[(((long)r * G + gg) * 2 + 1) * C + c]; }
+          for (int r = rl; r < nrep; r += P) { d0 += dsum[(((long)r * G + gg) * 2 + 0) * C + c]; d1 += dsum[(((long)r * G + gg) * 2 + 1) * C + c]; }
           ds = (float)d0; dh = (float)d1;
         } else {
-          for (int r = rl; r < nrep; r += 8) { ds += dscale[((long)r * G + gg) * C + c]; dh += dshift[((long)r * G + gg) * C + c]; }
+          for (int r = rl; r < nrep; r += P) { ds += dscale[((long)r * G + gg) * C + c]; dh += dshift[((long)r * G + gg) * C + c]; }
         }
       }
       __syncthreads();
-      s_red[0][rl][cl] = ds; s_red[1][rl][cl] = dh;
+      s_red[0][threadIdx.x] = ds; s_red[1][threadIdx.x] = dh;
       __syncthreads();
       if (rl == 0 && okc) {
         ds = 0.f; dh = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { ds += s_red[0][r][cl]; dh += s_red[1][r][cl]; }
+        for (int r = 0; r < P; ++r) { ds += s_red[0][r * ncp + cl]; dh += s_red[1][r * ncp + cl]; }
         const float gm = gamma ? gamma[c] : 1.f;
         const float mu = mean[gg * C + c], inv = invstd[gg * C + c];
         const float t = ds - mu * dh;

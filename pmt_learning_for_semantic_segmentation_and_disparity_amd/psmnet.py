@@ -26,10 +26,10 @@ def convbn_3d(in_planes, out_planes, kernel_size, stride, pad):
                          nn.BatchNorm3d(out_planes))
 
 
-def _run2d(seq, x, act=0, residual=None, groups=1):
+def _run2d(seq, x, act=0, residual=None, groups=1, in_slot=None, res_slot=None):
     c = seq[0]
     return ops.conv_bn_act(x, c.weight, seq[1], kind='conv', stride=c.stride[0], dilation=c.dilation[0], padding=c.padding[0],
-                           act=act, residual=residual, groups=groups)
+                           act=act, residual=residual, groups=groups, in_slot=in_slot, res_slot=res_slot)
 
 
 def _run3d(seq, x, D, act=0, residual=None, groups=1):
@@ -50,9 +50,13 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x, groups=1):
-        out = _run2d(self.conv1[0], x, act=1, groups=groups)
+        # x feeds conv1 and (identity blocks) the skip add: in the backward pass conv2's node parks the skip gradient — its own
+        # incoming gradient, the fresh data gradient of whatever consumes the block — and conv1's data gradient is accumulated
+        # onto it by the convolution launch (ops.GradSlot) instead of autograd adding two full maps (22 blocks per step)
+        slot = ops.GradSlot(exclusive=True) if (self.downsample is None and torch.is_grad_enabled() and x.is_cuda and x.requires_grad) else None
+        out = _run2d(self.conv1[0], x, act=1, groups=groups, in_slot=slot)
         skip = _run2d(self.downsample, x, groups=groups) if self.downsample is not None else x
-        return _run2d(self.conv2, out, act=0, residual=skip, groups=groups)     # BN then += x, no ReLU
+        return _run2d(self.conv2, out, act=0, residual=skip, groups=groups, res_slot=slot)     # BN then += x, no ReLU
 
 
 class disparityregression(nn.Module):

@@ -186,8 +186,10 @@ def test_hip_psmnet192_matches_cpu_oracle():
     loss = sum(F.l1_loss(o, disp.cuda()) for o in outs) / 3
     loss.backward()
     for o, w in zip(outs, want):
-        assert float((o.detach().cpu() - w).abs().max()) <= 1e-3 * 192
+        # THE GATE is the relative bound (max-abs error over max-abs value, 1e-3: north star); the absolute line only says the
+        # same thing in pixels for a reader (1e-3 of the 192-level range = 0.19 px) and can never be the tighter one
         assert _rel(o.detach().cpu(), w) < 1e-3
+        assert float((o.detach().cpu() - w).abs().max()) <= 1e-3 * 192
     wl = float(sum(F.l1_loss(w, disp) for w in want) / 3)
     assert abs(float(loss) - wl) <= 1e-3 * wl
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)

@@ -206,12 +206,14 @@ int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* d
  * table).  items: HOST array, fields as the arguments of sdhip_conv2d_wgrad; every dw_packed / dbias must already be zero
  * (prezeroed semantics).  Results equal n calls of sdhip_conv2d_wgrad up to the order of the f32 atomic adds.  Nothing in
  * a training step reads a weight gradient before the optimizer (torch_implementation.py:389,724), so the step queues its
- * ~200 per-layer launches and issues them here after the backward pass (ops.StepContext.join). */
+ * ~200 per-layer launches and issues them here after the backward pass (ops.StepContext.join).
+ * max_workgroups > 0: every grid stays within that many workgroups (one round), leaving CUs to the kernels of another
+ * stream — the decoder's weight gradients run beside the latency-bound DenseNet backward chain that way; 0: fill the chip. */
 typedef struct SdhipWgradItem {
   const void* x; const void* dy; float* dw_packed; float* dbias; const float* in_scale; const float* in_shift;
   int B, H, W, Cin, ldx, Ho, Wo, Cout, lddy, kh, kw, stride, dil, pad_t, pad_l, D, Do, kd, sd, pad_d, in_relu, groups;
 } SdhipWgradItem;
-int sdhip_conv2d_wgrad_group(const SdhipWgradItem* items, int n, int dtype, void* stream);
+int sdhip_conv2d_wgrad_group(const SdhipWgradItem* items, int n, int max_workgroups, int dtype, void* stream);
 
 /* 1x1 convolution (+ bias, + activation) over the channel concatenation [x0 | x1] without materialising it; segment i is
  * read at pixel (h >> us_i, w >> us_i) of a (B, c_i, H >> us_i, W >> us_i) map, i.e. nearest-neighbour upsampled by

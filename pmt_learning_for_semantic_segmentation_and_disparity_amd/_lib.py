@@ -43,7 +43,7 @@ SIGNATURES = {
     "sdhip_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 27 + [_p],
     "sdhip_conv2d_fwd_phase": [_p, _p, _p, _p, _i, _i] + [_i] * 16 + [_p],
     "sdhip_conv2d_wgrad": [_p, _p, _p, _p, _p, _p] + [_i] * 24 + [_p],
-    "sdhip_conv2d_wgrad_group": [_p, _i, _i, _p],
+    "sdhip_conv2d_wgrad_group": [_p, _i, _i, _i, _p],
     "sdhip_conv1x1_cat_fwd": [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdhip_conv_pack_batch": [_p, _i, _i, _p],
     "sdhip_conv_unpack_batch": [_p, _i, _i, _p],
@@ -167,6 +167,8 @@ DIAG_NO_FUSED_BN = bool(_diag_switch("SDHIP_DIAG_NO_FUSED_BN"))
 DIAG_NO_SIDE = bool(_diag_switch("SDHIP_DIAG_NO_SIDE"))
 DIAG_NO_GRAD_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_GRAD_SLOTS"))
 DIAG_NO_WGRAD_GROUP = bool(_diag_switch("SDHIP_DIAG_NO_WGRAD_GROUP"))
+TUNE_WGRAD_OVERLAP = bool(_diag_switch("SDHIP_TUNE_WGRAD_OVERLAP"))     # measured and not kept as a default: see train.TrainStep
+TUNE_OVERLAP_WG = int(_diag_switch("SDHIP_TUNE_OVERLAP_WG") or 128)
 DIAG_NO_BN_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_BN_SLOTS"))
 TUNE_FUSE1_MAX_PIX = int(_diag_switch("SDHIP_TUNE_FUSE1_MAX_PIX") or 32768)
 TUNE_PRO_MAX_PIX = int(_diag_switch("SDHIP_TUNE_PRO_MAX_PIX") or 32768)

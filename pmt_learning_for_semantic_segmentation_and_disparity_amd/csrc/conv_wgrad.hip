@@ -525,14 +525,19 @@ namespace {
 // One grid for `k` (<= kWgfGroupMax) planned layers of one instantiation.  Tile shares per layer: every workgroup should
 // sweep for about the same time tau; tau is chosen by a sweep over the cost model of plan_wgf (sweep time per tile, closing
 // atomics per workgroup at the chip-wide atomic rate) against the number of workgroup slots.
-int launch_wgf_group(std::vector<WgfPlan>& pls, size_t lo, size_t hi, hipStream_t s) {
+int launch_wgf_group(std::vector<WgfPlan>& pls, size_t lo, size_t hi, hipStream_t s, int max_wg) {
   const int k = (int)(hi - lo);
-  if (k == 1) return launch_wgf_plan(pls[lo], s);
+  if (k == 1) {
+    if (max_wg > 0 && pls[lo].gx * pls[lo].gy > max_wg) pls[lo].gx = max_wg / pls[lo].gy > 0 ? max_wg / pls[lo].gy : 1;
+    return launch_wgf_plan(pls[lo], s);
+  }
   size_t lds = 0;
   int occ = 2;
   for (size_t i = lo; i < hi; ++i) { if (pls[i].lds > lds) lds = pls[i].lds; if (pls[i].occ < occ) occ = pls[i].occ; }
   if (2 * lds > 160 * 1024) occ = 1;
-  const int slots = 256 * occ;
+  // max_wg > 0: the grid must stay within that many workgroups in ONE round, so that it leaves CUs free for the kernels of
+  // another stream (the weight gradients of the decoder beside the latency-bound DenseNet backward chain)
+  const int slots = max_wg > 0 && max_wg < 256 * occ ? max_wg : 256 * occ;
   // Tile shares: for 1..4 rounds of `slots` workgroups, the smallest sweep time tau per workgroup whose shares fit the
   // budget (bisection), then the candidate with the best modelled time.  The grid must not spill a few workgroups past a
   // round: with uniform sweep times, 288 workgroups on 256 slots take two rounds (measured: 17 full-resolution layers in
@@ -556,7 +561,7 @@ int launch_wgf_group(std::vector<WgfPlan>& pls, size_t lo, size_t hi, hipStream_
     }
     return nwg;
   };
-  for (int rounds = 1; rounds <= 4; ++rounds) {
+  for (int rounds = 1; rounds <= (max_wg > 0 ? 1 : 4); ++rounds) {
     const long budget = (long)slots * rounds;
     double tl = 0.05, th = 1e5, tmax, atom;
     int gxs[kWgfGroupMax];
@@ -596,7 +601,7 @@ int launch_wgf_group(std::vector<WgfPlan>& pls, size_t lo, size_t hi, hipStream_
 
 }  // namespace
 
-extern "C" int sdhip_conv2d_wgrad_group(const SdhipWgradItem* items, int n, int dtype, void* stream) {
+extern "C" int sdhip_conv2d_wgrad_group(const SdhipWgradItem* items, int n, int max_workgroups, int dtype, void* stream) {
   SDHIP_CHECK_ARG(items && n > 0, "conv2d_wgrad_group: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   std::vector<WgfPlan> plans;
@@ -624,7 +629,7 @@ extern "C" int sdhip_conv2d_wgrad_group(const SdhipWgradItem* items, int n, int 
     const size_t per = (bucket.size() + nchunk - 1) / nchunk;
     for (size_t lo = 0; lo < bucket.size(); lo += per) {
       const size_t hi = lo + per < bucket.size() ? lo + per : bucket.size();
-      const int rc = launch_wgf_group(bucket, lo, hi, s);
+      const int rc = launch_wgf_group(bucket, lo, hi, s, max_workgroups);
       if (rc != SDHIP_OK) return rc;
     }
   }

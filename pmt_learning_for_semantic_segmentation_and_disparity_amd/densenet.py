@@ -175,6 +175,7 @@ class _DenseBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_slab_in, gS_in):
+        ops.overlap_point()      # the queued weight gradients may run beside this block's chain of small kernels
         layers = list(ctx.block.values())
         groups, slab = ctx.groups, ctx.slab
         B, C0, H, W, growth, mid, Ct, training, count = ctx.geom

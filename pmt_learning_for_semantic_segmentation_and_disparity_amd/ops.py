@@ -138,9 +138,12 @@ class StepContext:
         self.wq = []             # [(WgradItem fields...)] of the running step
         self.wq_keep = []        # operands of the queued launches
         self.wq_dt = None
+        # single GPU: the queue is flushed onto the side stream, with grids limited to part of the chip, when the backward pass
+        # reaches the DenseNet towers (overlap_point) — their ~400 small dependent kernels leave most CUs idle
+        self.overlap = False
 
-    def flush_wgrads(self):
-        """Issue the queued weight-gradient launches (grouped) on the current stream."""
+    def flush_wgrads(self, max_wg=0):
+        """Issue the queued weight-gradient launches (grouped) on the current stream; max_wg > 0 limits every grid."""
         if not self.wq:
             return
         import ctypes
@@ -151,11 +154,11 @@ class StepContext:
         n, dt = len(self.wq), self.wq_dt
         self.wq = []
         try:
-            call("sdhip_conv2d_wgrad_group", ctypes.cast(items, ctypes.c_void_p), n, dt, stream_ptr())
+            call("sdhip_conv2d_wgrad_group", ctypes.cast(items, ctypes.c_void_p), n, int(max_wg), dt, stream_ptr())
         finally:
             self.wq_keep.clear()
 
-    def flush_to_side(self, min_items=12):
+    def flush_to_side(self, min_items=12, max_wg=0):
         """Data parallel: the main stream spends most of the backward pass in latency-bound sync-BN exchanges — buckets of
         queued weight gradients run beside it on the side stream as soon as they are worth a grid."""
         if self.side is None or len(self.wq) < min_items:
@@ -164,7 +167,13 @@ class StepContext:
         self.side.wait_stream(main)                  # the queued operands were produced on the main stream
         self.keep.extend(self.wq_keep)               # the caching allocator must not recycle them before join()
         with torch.cuda.stream(self.side):
-            self.flush_wgrads()
+            self.flush_wgrads(max_wg)
+
+    def overlap_point(self):
+        """Called where the backward pass enters a long chain of small dependent kernels (a DenseNet block): what is queued
+        so far goes to the side stream in grids of at most TUNE_OVERLAP_WG workgroups, which leave the other CUs to the chain."""
+        if self.overlap:
+            self.flush_to_side(min_items=1, max_wg=_lib.TUNE_OVERLAP_WG)
 
     def join(self):
         """Call after backward, before the optimizer: the queued weight gradients are launched (grouped), the main stream
@@ -215,6 +224,12 @@ _ctx = [None]
 
 def set_step_context(ctx):
     _ctx[0] = ctx
+
+
+def overlap_point():
+    c = _ctx[0]
+    if c is not None:
+        c.overlap_point()
 
 
 def _zeros(shape, dtype, device):
@@ -634,7 +649,8 @@ def _wgrad_impl(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu
                      spec.kh, spec.kw, spec.stride, spec.dil, spec.pad_t, spec.pad_l) + tuple(spec.depth()) + (int(in_relu), groups))
         c.wq_keep.append((xv, g, in_scale, in_shift))
         c.wq_dt = dt
-        c.flush_to_side()
+        if not c.overlap:
+            c.flush_to_side()
     else:
         call("sdhip_conv2d_wgrad", ptr(xv), ptr(g), ptr(acc), ptr(dbias), ptr(in_scale), ptr(in_shift),
              B, H, W, Cin, ldx, spec.Ho, spec.Wo, Cout, ldg, spec.kh, spec.kw, spec.stride, spec.dil,

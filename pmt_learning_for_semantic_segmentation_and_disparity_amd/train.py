@@ -59,8 +59,13 @@ class TrainStep:
         # Weight gradients on a second captured stream: on one GPU every kernel fills the chip and the overlap buys nothing
         # (measured 31.8 ms without vs 32.5 ms with), but under data parallelism the main stream sits in ~400 latency-bound
         # sync-BN all-reduces per step — the weight gradients then run inside those waits.
+        # Single GPU, opt-in (SDHIP_TUNE_WGRAD_OVERLAP=1): the side stream carries the decoder's grouped weight gradients, in
+        # grids limited to part of the chip, beside the DenseNet backward chain (StepContext.overlap_point).  Measured on
+        # one box (ms/step): off 21.29 / 21.31; grids of 64 / 128 / 192 / 256 workgroups 27.5 / 21.9 / 21.5 / 21.7 — the chain's
+        # small latency-bound kernels lose what the overlap hides (~2.8 ms slower beside the streaming grids), as in round 2.
+        self.overlap_wgrad = world_size == 1 and use_side_stream is None and _lib.TUNE_WGRAD_OVERLAP and not _lib.DIAG_NO_WGRAD_GROUP
         if use_side_stream is None:
-            use_side_stream = world_size > 1
+            use_side_stream = world_size > 1 or self.overlap_wgrad
         self.use_side_stream = use_side_stream and not _lib.DIAG_NO_SIDE   # timing diagnostics only
         self.graph = None
         self.static = None
@@ -96,6 +101,7 @@ class TrainStep:
         self.ctx.direct_grads = True
         if self.use_side_stream:
             self.ctx.side = torch.cuda.Stream()
+            self.ctx.overlap = self.overlap_wgrad
         self.nbt_tensors = [t for t, _ in self.ctx.nbt]
         self.nbt_incs = [int(i) for _, i in self.ctx.nbt]
 

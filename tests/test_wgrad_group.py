@@ -38,7 +38,7 @@ def _run_single(L, dev):
     return acc, db
 
 
-def _run_group(layers, dev):
+def _run_group(layers, dev, max_wg=0):
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import _lib
     from pmt_learning_for_semantic_segmentation_and_disparity_amd._lib import call, stream_ptr
     items = (_lib.WgradItem * len(layers))()
@@ -52,7 +52,7 @@ def _run_group(layers, dev):
         for n, v in zip(names, vals):
             setattr(it, n, v)
         outs.append((acc, db))
-    call("sdhip_conv2d_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(layers), _lib.BF16, stream_ptr())
+    call("sdhip_conv2d_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(layers), max_wg, _lib.BF16, stream_ptr())
     return outs
 
 
@@ -79,15 +79,16 @@ def test_group_equals_per_layer_launches():
         _layer(dev, 2, 24, 40, 65, 64, 1, ldx=72, bias=True, seed=213),
     ]
     want = [_run_single(L, dev) for L in layers]
-    got = _run_group(layers, dev)
-    torch.cuda.synchronize()
-    for i, ((wa, wb), (ga, gb)) in enumerate(zip(want, got)):
-        n = float(wa.norm())
-        assert n > 0, i
-        err = float((ga - wa).norm()) / n
-        assert err < 2e-5, (i, layers[i]["geo"], err)          # f32 atomics in another order
-        if wb is not None:
-            assert float((gb - wb).abs().max()) <= 1e-4 * max(1.0, float(wb.abs().max())), i
+    for max_wg in (0, 96):                                       # 96: grids limited to a part of the chip (overlap mode)
+        got = _run_group(layers, dev, max_wg)
+        torch.cuda.synchronize()
+        for i, ((wa, wb), (ga, gb)) in enumerate(zip(want, got)):
+            n = float(wa.norm())
+            assert n > 0, i
+            err = float((ga - wa).norm()) / n
+            assert err < 2e-5, (i, max_wg, layers[i]["geo"], err)          # f32 atomics in another order
+            if wb is not None:
+                assert float((gb - wb).abs().max()) <= 1e-4 * max(1.0, float(wb.abs().max())), i
 
 
 @pytest.mark.gpu
@@ -97,7 +98,7 @@ def test_group_of_one_and_argument_errors():
     L = _layer(dev, 2, 32, 64, 64, 64, 3, seed=5)
     (wa, _), ((ga, _),) = _run_single(L, dev), _run_group([L], dev)
     assert float((ga - wa).norm()) <= 2e-5 * float(wa.norm())
-    rc = _lib._lib.sdhip_conv2d_wgrad_group(None, 3, _lib.BF16, None)
+    rc = _lib._lib.sdhip_conv2d_wgrad_group(None, 3, 0, _lib.BF16, None)
     assert rc == _lib.ERR_ARG and b"bad arguments" in _lib._lib.sdhip_last_error()
 
 

@@ -72,6 +72,9 @@ def build_model(dtype, name="minidsnetExt"):
     if name == "psmnet":
         from pmt_learning_for_semantic_segmentation_and_disparity_amd.psmnet import PSMNet
         return PSMNet(192).cuda().train()
+    if name == "minidsnetExt_cfg5":     # BASELINE config 5: ASPP + HANet, 19 Cityscapes classes (the HANet head is built, and as upstream unused with aspp=2)
+        return N.minidsnetExt(CFG(dropout=0.0, aspp=2, use_att=1, hanet=1), labels=19, pretrained=False, patch_type='1dcorr',
+                              backbone='densenet').cuda().train()
     m = N.minidsnetExt(CFG(dropout=0.0, aspp=0, use_att=1), labels=2, pretrained=False, patch_type='1dcorr', backbone='densenet')
     return m.cuda().train()
 
@@ -174,7 +177,8 @@ def ctypes_stream(s):
 
 # algorithmic work per stereo pair of one training step at 256x512 (forward MACs x 2 FLOP x 3 for fwd+dgrad+wgrad;
 # conv activation bytes, each conv reading its input and writing its output once, x 3); scaled by H*W
-WORK = {"minidsnetExt": (643.0e9, 2.3e9), "dsnet": (3 * 2 * 195.4e9, 2.3e9 * 195.4 / 107.17), "psmnet": (1108.2e9, 3 * 0.73e9 + 3 * 0.4e9)}
+WORK = {"minidsnetExt": (643.0e9, 2.3e9), "dsnet": (3 * 2 * 195.4e9, 2.3e9 * 195.4 / 107.17), "psmnet": (1108.2e9, 3 * 0.73e9 + 3 * 0.4e9),
+        "minidsnetExt_cfg5": (3 * 2 * 98.1e9, 2.3e9 * 98.1 / 107.17)}     # aspp=2: 98.1 GMAC forward per pair at 256x512
 
 
 def step_roofline(model, B, H, W, ms, dtype):
@@ -200,8 +204,10 @@ def time_model(name, dtype, B, H, W, steps, warmup, world=1, pg=None, use_graph=
         loss_fn = lambda outs, seg, disp: _ops.mean_l1_loss(outs, disp[:, 0])
     elif name in ("dsnet", "dsnetnoCorr"):
         loss_fn = lambda outs, seg, disp: _ops.train_loss(outs[0], outs[1], outs[2], seg, disp, True)
+    elif name == "minidsnetExt_cfg5":   # the cityscapes rules: void pixels, disp > 0 mask
+        loss_fn = lambda outs, seg, disp: _ops.train_loss(outs[0], outs[1], outs[2], seg, disp, True, True, True)
     step = TrainStep(model, dtype=dtype, use_graph=use_graph, world_size=world, process_group=pg, loss_fn=loss_fn)
-    batch = synthetic_batch(B, H, W, seed=seed)
+    batch = synthetic_batch(B, H, W, labels=19 if name == "minidsnetExt_cfg5" else 2, seed=seed)
     for _ in range(warmup):
         loss = step(*batch)
     torch.cuda.synchronize()
@@ -367,17 +373,20 @@ def main():
         if world == 1 and not a.no_secondary and a.model == "minidsnetExt" and not a.no_graph:
             sec = []
             f32 = torch.float32
-            for name, sb, sdt, label in (
-                    ("dsnet", a.batch, dtype, "dsnet = PyTorch port of baseline_SDnet_small_fixed (BASELINE config 2 as literally named)"),
-                    ("psmnet", 8, dtype, "PSMNet(192) stacked hourglass, loss mean L1 x3 (BASELINE config 3, SURVEY 8d batch 8)"),
-                    ("minidsnetExt", a.batch, f32, "minidsnetExt, the headline workload on the fp32 path (the arithmetic north_star's 1e-3 "
-                                                   "parity gate is stated for: f32 activations, v_mfma_f32_16x16x4_f32)")):
+            for name, sb, sdt, sh, sw, label in (
+                    ("dsnet", a.batch, dtype, a.height, a.width, "dsnet = PyTorch port of baseline_SDnet_small_fixed (BASELINE config 2 as literally named)"),
+                    ("psmnet", 8, dtype, a.height, a.width, "PSMNet(192) stacked hourglass, loss mean L1 x3 (BASELINE config 3, SURVEY 8d batch 8)"),
+                    ("minidsnetExt", a.batch, f32, a.height, a.width, "minidsnetExt, the headline workload on the fp32 path (the arithmetic north_star's 1e-3 "
+                                                                     "parity gate is stated for: f32 activations, v_mfma_f32_16x16x4_f32)"),
+                    ("psmnet", 4, dtype, 512, 960, "PSMNet(192) at BASELINE config 4's per-GPU workload (960x512, batch 4 per GPU) on ONE GPU"),
+                    ("minidsnetExt_cfg5", 4, dtype, 512, 1024, "minidsnetExt(aspp=2, hanet=1, 19 classes) at BASELINE config 5's image size (1024x512), "
+                                                               "batch 4, cityscapes loss rules, on ONE GPU")):
                 sname = "f32" if sdt == f32 else a.dtype
                 sys.stderr.write("[bench] secondary: %s B=%d %s\n" % (name, sb, sname)); sys.stderr.flush()
-                ms, lv, gr = time_model(name, sdt, sb, a.height, a.width, a.secondary_steps, 1)
-                sec.append({"workload": "%s, %dx%d, batch %d, %s, %s" % (label, a.width, a.height, sb, sname, "hipGraph" if gr else "eager"),
+                ms, lv, gr = time_model(name, sdt, sb, sh, sw, a.secondary_steps, 1)
+                sec.append({"workload": "%s, %dx%d, batch %d, %s, %s" % (label, sw, sh, sb, sname, "hipGraph" if gr else "eager"),
                             "dtype": sname, "value": round(sb / ms * 1e3, 2), "unit": "stereo-pairs/s", "ms_per_step": round(ms, 3),
-                            "steps": a.secondary_steps, "loss": round(lv, 5), "step_roofline": step_roofline(name, sb, a.height, a.width, ms, sname)})
+                            "steps": a.secondary_steps, "loss": round(lv, 5), "step_roofline": step_roofline(name, sb, sh, sw, ms, sname)})
             out["secondary"] = sec
         if world == 1 and not a.no_cpu_baseline and a.model == "minidsnetExt":
             out["cpu_baseline"] = cpu_baseline(2, a.height, a.width, a.cpu_steps, a.cpu_threads, a.cpu_warmup)

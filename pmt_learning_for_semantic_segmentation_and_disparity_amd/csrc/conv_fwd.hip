@@ -500,13 +500,14 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     return SDHIP_OK;
   }
   // ---- one input channel fanned out to <= 64 output channels (conv_thin.h): taps as the MFMA reduction axis ----
-  if (!ps && !bx && !addend && omul == 1 && dtype == SDHIP_BF16 && fanout_ok(Cin, Cout, kh * kw, stride, kd, ldy, y) && D == 1 && Do == 1 && !in_scale &&
+  if (!ps && !bx && !addend && omul == 1 && dtype == SDHIP_BF16 && fanout_ok(Cin, Cout, kh * kw, stride, kd, sd, ldy, y) && !in_scale &&
       !accumulate && !stats && !bias && act == 0 && (kh - 1) * dil <= 31 && (kw - 1) * dil <= 31 && (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) < (1L << 31) &&
       B <= 65535 && !dg.conv_no_thin) {
     FanArgs t;
     t.x = x; t.wp = wpacked; t.y = y;
     t.B = B; t.H = H; t.W = W; t.Ho = Ho; t.Wo = Wo; t.kh = kh; t.kw = kw; t.dil = dil; t.pad_t = pad_t; t.pad_l = pad_l;
     t.ldx = ldx; t.Cout = Cout; t.Mpad = a.Mpad; t.ldy = ldy;
+    t.D = D; t.Do = Do; t.kd = kd; t.pad_d = pad_d; t.dpw = 1; t.zsegs = Do;
     return launch_fanout(t, s);
   }
   // ---- 1x1 as a streaming GEMM (conv_gemm.h): bf16, plain stride-1 1x1 over whole images ----

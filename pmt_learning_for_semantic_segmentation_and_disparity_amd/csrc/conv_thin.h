@@ -227,92 +227,118 @@ __global__ __launch_bounds__(256) void conv_thin_wgrad_tiled_kernel(const ThinWg
 
 // ---- ONE input channel -> up to 64 output channels, <= 32 taps, stride 1, bf16 --------------------------------------
 // The data gradient of a convolution with a single output map (the disparity head `ConvTranspose2dSame(64, 1, 5)` and the
-// 1x1 attention gates `conv2dSame(64, 1, 1)`, models/dsnet_t2.py: dispoutConv / conv1d_at_*): y[p][m] = sum_t x[p + off_t] *
-// w[m][t].  On the halo-tile kernels the one real channel rides in a 32-channel k-step (1/32 of every MFMA) — 159 us for
-// a layer whose only real work is writing 134 MB.  Here the TAPS are the reduction axis: one v_mfma_f32_16x16x32_bf16
-// per (16 pixels x 16 output channels) with k = tap index; the pixel operand is gathered from a scalar halo tile in LDS.
+// 1x1 attention gates `conv2dSame(64, 1, 1)`, models/dsnet_t2.py: dispoutConv / conv1d_at_*; the last 3x3x3 of PSMNet's
+// classif1-3, models/stackhourglass.py:90-102): y[p][m] = sum_t x[p + off_t] * w[m][t].  On the halo-tile kernels the one
+// real channel rides in a 32-channel k-step (1/32 of every MFMA) — 159 us for a layer whose only real work is writing
+// 134 MB.  Here the TAPS are the reduction axis: one v_mfma_f32_16x16x32_bf16 per (16 pixels x 16 output channels) with
+// k = tap index (kd*kh*kw <= 32); the pixel operand is gathered from a scalar halo tile in LDS.  Volumes: one workgroup
+// walks `dpw` consecutive output slices of its 8x32 tile (weights and their fragments staged once, dpw + kd - 1 halo
+// slices resident).
 struct FanArgs {
   const void* x; const void* wp; void* y;
   int B, H, W, Ho, Wo, kh, kw, dil, pad_t, pad_l;
   int ldx, Cout, Mpad, ldy;
+  int D, Do, kd, pad_d, dpw, zsegs;     // volume depth / output depth / depth taps / front padding / slices per workgroup / ceil(Do/dpw)
 };
+
+constexpr int kFanHalo = 4096;          // scalar halo elements in LDS
 
 __global__ __launch_bounds__(256) void conv_fanout_kernel(const FanArgs p) {
   constexpr int TH = 8, TW = 32, CK = 64;
   __shared__ __attribute__((aligned(16))) bf16_t wl[64][32];      // [output channel][tap], zero beyond the kernel / Cout
-  __shared__ bf16_t xt[(TH + 31) * (TW + 31) + 8];                 // halo tile of the single input map (taps <= 32 => extent <= 31 more)
+  __shared__ bf16_t xt[kFanHalo + 8];                              // halo tiles of the single input map, slice after slice
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
-  const int Tn = p.kh * p.kw;
+  const int T2 = p.kh * p.kw, Tn = T2 * p.kd;
   const int tiles_w = (p.Wo + TW - 1) / TW;
   const int ty = blockIdx.x / tiles_w, oh0 = ty * TH, ow0 = (blockIdx.x - ty * tiles_w) * TW;
-  const int b = blockIdx.y;
-  const int IH = TH + (p.kh - 1) * p.dil, IW = TW + (p.kw - 1) * p.dil;
-  const bf16_t* xb = (const bf16_t*)p.x + (long)b * p.H * p.W * p.ldx;
+  const int b = blockIdx.y / p.zsegs, z0 = (blockIdx.y - b * p.zsegs) * p.dpw;
+  const int nz = min(p.dpw, p.Do - z0);
+  const int IH = TH + (p.kh - 1) * p.dil, IW = TW + (p.kw - 1) * p.dil, IS = IH * IW;
+  const bf16_t* xb = (const bf16_t*)p.x + (long)b * p.D * p.H * p.W * p.ldx;
   for (int i = tid; i < 64 * 32; i += 256) {
     const int m = i >> 5, t = i & 31;
-    wl[m][t] = (m < p.Cout && t < Tn) ? ((const bf16_t*)p.wp)[((long)t * p.Mpad + m) * CK] : (bf16_t)0;   // packed [t][Mpad][64], channel 0
+    wl[m][t] = (m < p.Cout && t < Tn) ? ((const bf16_t*)p.wp)[((long)t * p.Mpad + m) * CK] : (bf16_t)0;   // packed [kd][1][T2][Mpad][64], channel 0
   }
-  for (int i = tid; i < IH * IW; i += 256) {
-    const int ih = i / IW, iw = i - ih * IW;
-    const int gh = oh0 - p.pad_t + ih, gw = ow0 - p.pad_l + iw;
-    xt[i] = (gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) ? xb[((long)gh * p.W + gw) * p.ldx] : (bf16_t)0;
+  const int nsl = nz + p.kd - 1;
+  for (int i = tid; i < nsl * IS; i += 256) {
+    const int sl = i / IS, r = i - sl * IS;
+    const int ih = r / IW, iw = r - ih * IW;
+    const int gz = z0 - p.pad_d + sl, gh = oh0 - p.pad_t + ih, gw = ow0 - p.pad_l + iw;
+    xt[i] = (gz >= 0 && gz < p.D && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) ? xb[(((long)gz * p.H + gh) * p.W + gw) * p.ldx] : (bf16_t)0;
   }
   __syncthreads();
-  // tap t of this lane's k-slice (8 taps: 8*lg .. 8*lg+7): offset inside the halo tile, taps past the kernel read slot 0
+  // tap t of this lane's k-slice (8 taps: 8*lg .. 8*lg+7): offset inside the halo tiles, taps past the kernel read slot 0
   // (their weights are zero)
   int toff[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int t = 8 * lg + j;
-    const int khi = t / p.kw, kwi = t - khi * p.kw;
-    toff[j] = t < Tn ? khi * p.dil * IW + kwi * p.dil : 0;
+    const int kdi = t / T2, t2 = t - kdi * T2;
+    const int khi = t2 / p.kw, kwi = t2 - khi * p.kw;
+    toff[j] = t < Tn ? kdi * IS + khi * p.dil * IW + kwi * p.dil : 0;
   }
   u32x4 af[4];                                                     // weights: lane (l15 = output channel of the tile, lg = k-slice)
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const u32x4*>(&wl[mi * 16 + l15][8 * lg]);
-  bf16_t* yb = (bf16_t*)p.y + (long)b * p.Ho * p.Wo * p.ldy;
+  for (int z = 0; z < nz; ++z) {
+    bf16_t* yb = (bf16_t*)p.y + ((long)b * p.Do + z0 + z) * p.Ho * p.Wo * p.ldy;
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {                                 // wave: tile rows 2*wave, 2*wave + 1; two 16-pixel column blocks each
-    const int r = 2 * wave + (ni >> 1), c = (ni & 1) * 16 + l15;
-    const int base = r * IW + c;
-    unsigned short v[8];
+    for (int ni = 0; ni < 4; ++ni) {                               // wave: tile rows 2*wave, 2*wave + 1; two 16-pixel column blocks each
+      const int r = 2 * wave + (ni >> 1), c = (ni & 1) * 16 + l15;
+      const int base = z * IS + r * IW + c;
+      unsigned short v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = xt[base + toff[j]];
-    const u32x4 bfrag = u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
-                              (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
-    const int oh = oh0 + r, ow = ow0 + c;
-    const bool valid = oh < p.Ho && ow < p.Wo;
-    bf16_t* dst = yb + ((long)oh * p.Wo + ow) * p.ldy;
-    f32x4 acc[4];
+      for (int j = 0; j < 8; ++j) v[j] = xt[base + toff[j]];
+      const u32x4 bfrag = u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                                (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+      const int oh = oh0 + r, ow = ow0 + c;
+      const bool valid = oh < p.Ho && ow < p.Wo;
+      bf16_t* dst = yb + ((long)oh * p.Wo + ow) * p.ldy;
+      f32x4 acc[4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (mi * 16 < p.Mpad) Mma<bf16_t>::run(acc[mi], af[mi], bfrag);   // uniform
-    }
-    // the (up to) four 32-byte pieces of a pixel's line in consecutive stores: they merge in L2 (see conv_band.h)
+      for (int mi = 0; mi < 4; ++mi) {
+        acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (mi * 16 < p.Mpad) Mma<bf16_t>::run(acc[mi], af[mi], bfrag);   // uniform
+      }
+      // the (up to) four 32-byte pieces of a pixel's line in consecutive stores: they merge in L2 (see conv_band.h)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      if (mi * 16 < p.Mpad) {
-        const int co = mi * 16 + 4 * lg;
-        if (valid && co + 3 < p.Cout) {
-          *reinterpret_cast<u32x2*>(dst + co) = u32x2{pack2bf(acc[mi][0], acc[mi][1]), pack2bf(acc[mi][2], acc[mi][3])};
-        } else if (valid) {
+      for (int mi = 0; mi < 4; ++mi) {
+        if (mi * 16 < p.Mpad) {
+          const int co = mi * 16 + 4 * lg;
+          if (valid && co + 3 < p.Cout) {
+            *reinterpret_cast<u32x2*>(dst + co) = u32x2{pack2bf(acc[mi][0], acc[mi][1]), pack2bf(acc[mi][2], acc[mi][3])};
+          } else if (valid) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (co + e < p.Cout) dst[co + e] = f2bf(acc[mi][e]);
+            for (int e = 0; e < 4; ++e)
+              if (co + e < p.Cout) dst[co + e] = f2bf(acc[mi][e]);
+          }
         }
       }
     }
   }
 }
 
-inline bool fanout_ok(int Cin, int Cout, int T, int stride, int kd, int ldy, const void* y) {
-  return Cin == 1 && Cout <= 64 && Cout >= 8 && T <= 32 && stride == 1 && kd == 1 && ldy % 4 == 0 && ((uintptr_t)y & 7) == 0;
+inline bool fanout_ok(int Cin, int Cout, int T, int stride, int kd, int sd, int ldy, const void* y) {
+  return Cin == 1 && Cout <= 64 && Cout >= 8 && T * kd <= 32 && stride == 1 && sd == 1 && ldy % 4 == 0 && ((uintptr_t)y & 7) == 0;
 }
 
-inline int launch_fanout(const FanArgs& a, hipStream_t s) {
-  dim3 grid(sdhip_cdiv(a.Ho, 8) * sdhip_cdiv(a.Wo, 32), a.B);
+// slices per workgroup: as many as the halo buffer holds, at most 8, and no fewer workgroups than ~4 per CU
+inline int fanout_dpw(const FanArgs& a) {
+  const int IS = (8 + (a.kh - 1) * a.dil) * (32 + (a.kw - 1) * a.dil);
+  int dpw = kFanHalo / IS - (a.kd - 1);
+  if (dpw > 8) dpw = 8;
+  if (dpw > a.Do) dpw = a.Do;
+  const long tiles = (long)sdhip_cdiv(a.Ho, 8) * sdhip_cdiv(a.Wo, 32) * a.B;
+  while (dpw > 1 && tiles * sdhip_cdiv(a.Do, dpw) < 1024) --dpw;
+  return dpw;
+}
+
+inline int launch_fanout(FanArgs a, hipStream_t s) {
+  a.dpw = fanout_dpw(a);
+  if (a.dpw < 1) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv fan-out: halo of a %dx%dx%d kernel with dilation %d exceeds the tile buffer", a.kd, a.kh, a.kw, a.dil);
+  a.zsegs = sdhip_cdiv(a.Do, a.dpw);
+  dim3 grid(sdhip_cdiv(a.Ho, 8) * sdhip_cdiv(a.Wo, 32), a.B * a.zsegs);
   hipLaunchKernelGGL(conv_fanout_kernel, grid, dim3(256), 0, s, a);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;

@@ -70,6 +70,33 @@ def test_hip_conv3d_matches_torch(cin, cout, stride, D, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,co,D,H,W", [(2, 32, 11, 19, 45), (1, 32, 48, 64, 128), (2, 16, 3, 8, 32)])
+def test_hip_conv3d_bf16_single_map_head(B, co, D, H, W):
+    """The 3x3x3 convolution to ONE map that ends classif1-3 (models/stackhourglass.py:90-102) in bf16: its data gradient is
+    the fan-out kernel over volumes (conv_thin.h: 27 taps as the MFMA reduction axis, several depth slices per workgroup);
+    forward, data gradient and weight gradient against f32 ATen on the same bf16-rounded operands."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + D)
+    x = torch.randn(B, co, D, H, W, generator=g).bfloat16()
+    w = (torch.randn(1, co, 3, 3, 3, generator=g) * 0.1)
+    gy = torch.randn(B, 1, D, H, W, generator=g).bfloat16()
+    xr = x.float().requires_grad_(True)
+    wr = w.bfloat16().float().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, padding=1)
+    yr.backward(gy.float())
+    wd = w.cuda().requires_grad_(True)
+    xd = _vol_to_images(x.cuda()).requires_grad_(True)
+    yd, Do = ops.conv3d(xd, D, wd, 1, 1)
+    assert Do == D and yd.dtype == torch.bfloat16
+    yd.backward(_vol_to_images(gy.cuda()))
+    torch.cuda.synchronize()
+    tol = 2.0 ** -7
+    assert _rel(_images_to_vol(yd, B).float().cpu(), yr.detach()) < tol
+    assert _rel(_images_to_vol(xd.grad, B).float().cpu(), xr.grad) < tol
+    assert _rel(wd.grad.float().cpu(), wr.grad) < tol
+
+
+@pytest.mark.gpu
 def test_hip_deconv3d_bn_matches_torch():
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
     torch.manual_seed(0)

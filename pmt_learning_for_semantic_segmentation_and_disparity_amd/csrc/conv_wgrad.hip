@@ -18,6 +18,7 @@
 #include "conv_common.h"
 #include "conv_wgrad_fast.h"
 #include "conv_wgrad_half.h"
+#include "conv_wgrad_single.h"
 #include "conv_thin.h"
 #include <algorithm>
 #include <vector>
@@ -464,6 +465,16 @@ static int wgrad_one(const void* x, const void* dy, float* dw_packed, float* dbi
     SDHIP_LAUNCH_CHECK();
     return SDHIP_OK;
   }
+  // ---- one output map, 9..32 input channels, <= 32 taps (conv_wgrad_single.h): taps as the MFMA row axis ----
+  if (dtype == SDHIP_BF16 && single_wgrad_ok(Cin, Cout, T, stride, dil, kd, sd, ldx, x) && !in_scale && !dbias && !sdhip_diag().conv_no_thin) {
+    SingleWgArgs t;
+    t.x = x; t.dy = dy; t.dwp = dw_packed;
+    t.B = B; t.H = H; t.W = W; t.Ho = Ho; t.Wo = Wo; t.kh = kh; t.kw = kw; t.pad_t = pad_t; t.pad_l = pad_l;
+    t.D = D; t.Do = Do; t.kd = kd; t.pad_d = pad_d;
+    t.Cin = Cin; t.ldx = ldx; t.lddy = lddy; t.Mpad = a.Mpad; t.dpw = 1; t.zsegs = D;
+    const int rc = launch_single_wgrad(t, s);
+    if (rc != 1) return rc;                     // 1: halo does not fit -> the kernels below
+  }
   // ---- bf16 fast path (conv_wgrad_fast.h): 16-byte-aligned pixels on both operands ----
   if (dtype == SDHIP_BF16 && a.vec_x && a.vec_dy && (long)H * W * ldx < (1L << 31) && (long)Ho * Wo * lddy < (1L << 31) &&
       !sdhip_diag().wgrad_generic) {
@@ -509,6 +520,35 @@ static int wgrad_one(const void* x, const void* dy, float* dw_packed, float* dbi
   return maxt == 9 ? launch_tile<float, 9, 32>(a, wide, s) : launch_tile<float, 25, 32>(a, wide, s);
 }
 
+// One layer, possibly as two half layers: 64 input channels into <= 32 output channels, 3x3 (x3), stride 1 (dres0[0] of PSMNet,
+// models_psmnet/stackhourglass.py:59: the 64-channel cost volume into 32) is the sum of two 32-channel layers over channel
+// halves of the same pixels — x + 32 elements, the same pixel stride — whose gradients are the column halves [0,32) / [32,64)
+// of the same packed rows [kd][1][9][Mpad][64]: both halves run on the 64-byte-row kernel (conv_wgrad_half.h) instead of the
+// 128-byte-row one (2.04 -> 2 x 0.3 ms at 4 x 48 x 128 x 240).  plans == nullptr: launch now; otherwise fast-path layers are planned.
+static int wgrad_layer(const void* x, const void* dy, float* dw_packed, float* dbias,
+                       const float* in_scale, const float* in_shift,
+                       int B, int H, int W, int Cin, int ldx,
+                       int Ho, int Wo, int Cout, int lddy,
+                       int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                       int D, int Do, int kd, int sd, int pad_d,
+                       int in_relu, int groups, int prezeroed, int dtype, void* stream, std::vector<WgfPlan>* plans) {
+  auto one = [&](const void* xx, float* dw, int cin, int prez) {
+    WgfPlan pl;
+    bool planned = false;
+    const int rc = wgrad_one(xx, dy, dw, dbias, in_scale, in_shift, B, H, W, cin, ldx, Ho, Wo, Cout, lddy, kh, kw, stride, dil, pad_t, pad_l,
+                             D, Do, kd, sd, pad_d, in_relu, groups, prez, dtype, stream, plans ? &pl : nullptr, plans ? &planned : nullptr);
+    if (rc == SDHIP_OK && planned) plans->push_back(pl);
+    return rc;
+  };
+  const bool halves = dtype == SDHIP_BF16 && x && dw_packed && Cin == 64 && Cout <= 32 && kh == 3 && kw == 3 && stride == 1 && dil == 1 && sd == 1 &&
+                      (kd == 3 || (kd == 1 && sdhip_diag().wgrad_split2d)) && !in_scale && !dbias && Wo >= 24 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 &&
+                      !sdhip_diag().wgrad_no_half32;
+  if (!halves) return one(x, dw_packed, Cin, prezeroed);
+  const int rc = one(x, dw_packed, 32, prezeroed);           // (clears all 64 columns when asked to: one 64-channel chunk either way)
+  if (rc != SDHIP_OK) return rc;
+  return one((const bf16_t*)x + 32, dw_packed + 32, 32, 1);
+}
+
 extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packed, float* dbias,
                                   const float* in_scale, const float* in_shift,
                                   int B, int H, int W, int Cin, int ldx,
@@ -516,8 +556,8 @@ extern "C" int sdhip_conv2d_wgrad(const void* x, const void* dy, float* dw_packe
                                   int kh, int kw, int stride, int dil, int pad_t, int pad_l,
                                   int D, int Do, int kd, int sd, int pad_d,
                                   int in_relu, int groups, int prezeroed, int dtype, void* stream) {
-  return wgrad_one(x, dy, dw_packed, dbias, in_scale, in_shift, B, H, W, Cin, ldx, Ho, Wo, Cout, lddy, kh, kw, stride, dil, pad_t, pad_l,
-                   D, Do, kd, sd, pad_d, in_relu, groups, prezeroed, dtype, stream, nullptr, nullptr);
+  return wgrad_layer(x, dy, dw_packed, dbias, in_scale, in_shift, B, H, W, Cin, ldx, Ho, Wo, Cout, lddy, kh, kw, stride, dil, pad_t, pad_l,
+                     D, Do, kd, sd, pad_d, in_relu, groups, prezeroed, dtype, stream, nullptr);
 }
 
 namespace {
@@ -608,13 +648,10 @@ extern "C" int sdhip_conv2d_wgrad_group(const SdhipWgradItem* items, int n, int 
   plans.reserve(n);
   for (int i = 0; i < n; ++i) {
     const SdhipWgradItem& it = items[i];
-    WgfPlan pl;
-    bool planned = false;
-    const int rc = wgrad_one(it.x, it.dy, it.dw_packed, it.dbias, it.in_scale, it.in_shift, it.B, it.H, it.W, it.Cin, it.ldx, it.Ho, it.Wo,
-                             it.Cout, it.lddy, it.kh, it.kw, it.stride, it.dil, it.pad_t, it.pad_l, it.D, it.Do, it.kd, it.sd, it.pad_d,
-                             it.in_relu, it.groups, 1, dtype, stream, &pl, &planned);
+    const int rc = wgrad_layer(it.x, it.dy, it.dw_packed, it.dbias, it.in_scale, it.in_shift, it.B, it.H, it.W, it.Cin, it.ldx, it.Ho, it.Wo,
+                               it.Cout, it.lddy, it.kh, it.kw, it.stride, it.dil, it.pad_t, it.pad_l, it.D, it.Do, it.kd, it.sd, it.pad_d,
+                               it.in_relu, it.groups, 1, dtype, stream, &plans);
     if (rc != SDHIP_OK) return rc;
-    if (planned) plans.push_back(pl);
   }
   // buckets = instantiations, in order of first appearance; <= kWgfGroupMax layers per grid
   std::vector<char> done(plans.size(), 0);

@@ -104,11 +104,13 @@ def test_group_of_one_and_argument_errors():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(2, 1, 37, 70, 32, 32), (1, 1, 8, 32, 8, 16), (2, 1, 64, 128, 24, 32),
-                                              (1, 5, 9, 40, 32, 32), (2, 3, 6, 33, 16, 24), (1, 2, 4, 24, 32, 8)])
+                                              (1, 5, 9, 40, 32, 32), (2, 3, 6, 33, 16, 24), (1, 2, 4, 24, 32, 8),
+                                              (1, 4, 10, 50, 64, 32), (2, 2, 5, 24, 64, 16)])
 def test_half_row_kernel_matches_f32_contraction(B, D, H, W, Cin, Cout):
     """conv_wgrad_half.h (64-byte LDS rows, all depth taps per workgroup; <= 32 channels on both sides, 3x3 / 3x3x3, stride 1,
     padding 1): the weight gradient against ATen's f32 contraction of the same bf16-rounded operands — ragged tiles, channel
-    counts below 32, depth taps that leave the volume, and the same layer through the general kernel (SDHIP_WGRAD_NO_HALF32)."""
+    counts below 32, depth taps that leave the volume, 64 input channels as two half layers (dres0[0] of PSMNet: wgrad_layer in
+    conv_wgrad.hip), and the same layer through the general kernel (SDHIP_WGRAD_NO_HALF32)."""
     import os
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops, _lib
     torch.manual_seed(B * 100 + D * 10 + Cin)
@@ -138,6 +140,49 @@ def test_half_row_kernel_matches_f32_contraction(B, D, H, W, Cin, Cout):
     _lib.reload_diag()
     n = float(want.norm())
     assert n > 0
+    assert float((got[""] - want).norm()) / n < 2e-3, float((got[""] - want).norm()) / n
+    assert float((got["1"] - want).norm()) / n < 2e-3
+    assert float((got[""] - got["1"]).norm()) / n < 1e-4          # same products, another summation order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D,H,W,Cin,k", [(2, 1, 37, 70, 32, 5), (1, 1, 16, 40, 24, 3), (2, 5, 9, 45, 32, 3), (1, 11, 8, 32, 16, 3),
+                                          (1, 20, 24, 64, 32, 3)])
+def test_single_map_wgrad_matches_f32_contraction(B, D, H, W, Cin, k):
+    """conv_wgrad_single.h (ONE output map, 9..32 input channels, <= 32 taps: taps as the MFMA row axis, dy gathered from a
+    scalar halo; classif1-3 of PSMNet end in such a layer) against ATen's f32 contraction of the same bf16-rounded operands,
+    and against the same layer through the general kernels (SDHIP_CONV_NO_THIN): ragged tiles, depth taps that leave the
+    volume, several slices per workgroup."""
+    import os
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops, _lib
+    torch.manual_seed(B * 100 + D * 10 + Cin)
+    dev = torch.device("cuda:0")
+    three = D > 1
+    pad = k // 2
+    x = torch.randn(B, Cin, D, H, W, device=dev).to(torch.bfloat16)
+    g = (torch.randn(B, 1, D, H, W, device=dev) * 0.1).to(torch.bfloat16)
+    if three:
+        w = torch.zeros(1, Cin, k, k, k, device=dev)
+        want = torch.nn.grad.conv3d_weight(x.float(), w.shape, g.float(), stride=1, padding=pad)
+    else:
+        w = torch.zeros(1, Cin, k, k, device=dev)
+        want = torch.nn.grad.conv2d_weight(x[:, :, 0].float(), w.shape, g[:, :, 0].float(), stride=1, padding=pad)
+    to_img = lambda t: t.permute(0, 2, 1, 3, 4).reshape(B * D, t.shape[1], H, W).contiguous(memory_format=torch.channels_last)
+    xi, gi = ops.aligned_view(to_img(x)), ops.aligned_view(to_img(g))
+    spec = ops.conv3d_spec(xi[0], D, w, 1, pad) if three else ops.conv_spec(xi[0], w, 'conv', 1, 1, pad)
+    ops.set_step_context(None)
+    got = {}
+    for sw in ("", "1"):
+        if sw:
+            os.environ["SDHIP_CONV_NO_THIN"] = sw
+        else:
+            os.environ.pop("SDHIP_CONV_NO_THIN", None)
+        _lib.reload_diag()
+        got[sw], _ = ops._wgrad_impl(xi[0], xi[1], gi[0], gi[1], w, None, spec, None, None, False, 1)
+    os.environ.pop("SDHIP_CONV_NO_THIN", None)
+    _lib.reload_diag()
+    n = float(want.norm())
+    assert n > 0 and got[""].shape == want.shape
     assert float((got[""] - want).norm()) / n < 2e-3, float((got[""] - want).norm()) / n
     assert float((got["1"] - want).norm()) / n < 2e-3
     assert float((got[""] - got["1"]).norm()) / n < 1e-4          # same products, another summation order

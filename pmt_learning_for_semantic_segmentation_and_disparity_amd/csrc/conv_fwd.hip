@@ -499,6 +499,18 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     SDHIP_LAUNCH_CHECK();
     return SDHIP_OK;
   }
+  // ---- 16..64 input channels into ONE output map (conv_thin.h): taps as the MFMA rows, fixed-order sum over taps ----
+  if (!ps && !bx && !addend && omul == 1 && dtype == SDHIP_BF16 && fanin_ok(Cin, Cout, kh, kw, stride, dil, kd, sd, ldx, x) && !in_scale && !accumulate &&
+      !stats && (long)H * W * ldx < (1L << 31) && !dg.conv_no_thin) {
+    FaninArgs t;
+    t.x = x; t.wp = wpacked; t.y = y; t.bias = bias;
+    t.B = B; t.H = H; t.W = W; t.Ho = Ho; t.Wo = Wo; t.kh = kh; t.kw = kw; t.pad_t = pad_t; t.pad_l = pad_l;
+    t.D = D; t.Do = Do; t.pad_d = pad_d;
+    t.Cin = Cin; t.ldx = ldx; t.ldy = ldy; t.Mpad = a.Mpad; t.act = act;
+    t.dpw = 1; t.zsegs = Do; t.npxp = 0; t.pitch = 0;
+    const int rc = launch_fanin(t, kd, s);
+    if (rc != 1) return rc;                     // 1: not launchable (LDS / grid limits) -> the kernels below
+  }
   // ---- one input channel fanned out to <= 64 output channels (conv_thin.h): taps as the MFMA reduction axis ----
   if (!ps && !bx && !addend && omul == 1 && dtype == SDHIP_BF16 && fanout_ok(Cin, Cout, kh * kw, stride, kd, sd, ldy, y) && !in_scale &&
       !accumulate && !stats && !bias && act == 0 && (kh - 1) * dil <= 31 && (kw - 1) * dil <= 31 && (long)sdhip_cdiv(Ho, 8) * sdhip_cdiv(Wo, 32) < (1L << 31) &&

@@ -344,4 +344,151 @@ inline int launch_fanout(FanArgs a, hipStream_t s) {
   return SDHIP_OK;
 }
 
+// ---- 16..64 input channels -> ONE output map, <= 32 taps, stride 1, bf16 (the mirror image of conv_fanout_kernel) --------
+// The last 3x3x3 of PSMNet's classif1-3 (models_psmnet/stackhourglass.py:90-102) and the single-map heads of the 2-D
+// networks (models/dsnet_t2.py: dispoutConv): on the halo-tile kernels the one real output channel owns a 16-row MFMA tile
+// (360 us for reading 377 MB once).  Here the TAPS are the MFMA rows: for every pixel q of the halo of an 8x32 output tile
+//     P[t][q] = sum_ci w[t][ci] * x[q][ci]              (A = weights in registers, B = 16-byte pieces of x straight from
+// global memory, one v_mfma_f32_16x16x32_bf16 per 16 pixels, 16 taps and 32 channels), P goes to LDS tap-major, and
+// output pixel o is the sum over taps of P[t][o + off_t] — a fixed order, so the result does not depend on timing.
+// Volumes (KD = 3): the workgroup walks input slices; slice s feeds depth tap k of output slice s - k + pad_d, three
+// running sums per thread; the next slice's pieces travel through registers behind the sums.
+struct FaninArgs {
+  const void* x; const void* wp; void* y; const float* bias;
+  int B, H, W, Ho, Wo, kh, kw, pad_t, pad_l;
+  int D, Do, pad_d;
+  int Cin, ldx, ldy, Mpad, act;
+  int dpw, zsegs, npxp, pitch;           // output slices per workgroup / ceil(Do / dpw) / halo pixels rounded up to 16 / floats per tap row of P
+};
+
+constexpr int kFaninMaxNT = 7;           // 16-pixel halo blocks per wave: halo <= 448 pixels
+
+template <int KD, int NK>
+__global__ __launch_bounds__(256) void conv_fanin_kernel(const FaninArgs p) {
+  constexpr int TH = 8, TW = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fan_smem[];
+  float* const P = reinterpret_cast<float*>(fan_smem);              // [tap][pitch]: pitch % 16 == 4, the four tap rows a wave writes at once fall on different banks
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int T2 = p.kh * p.kw, Tn = T2 * KD;
+  const int tiles_w = (p.Wo + TW - 1) / TW;
+  const int ty = blockIdx.x / tiles_w, oh0 = ty * TH, ow0 = (blockIdx.x - ty * tiles_w) * TW;
+  const int b = blockIdx.y / p.zsegs, z0 = (blockIdx.y - b * p.zsegs) * p.dpw;
+  const int nz = min(p.dpw, p.Do - z0);
+  const int IW = TW + p.kw - 1, NPX = (TH + p.kh - 1) * IW;
+  const int nblk = p.npxp >> 4;
+  const bf16_t* xb = (const bf16_t*)p.x + (long)b * p.D * p.H * p.W * p.ldx;
+
+  // weights: lane (l15 = tap of the 16-row tile, lg = 8-channel slice of the 32-channel k-step)
+  u32x4 af[2][NK];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int t = mt * 16 + l15, ch = ks * 32 + 8 * lg;
+      af[mt][ks] = (t < Tn && ch < p.Cin) ? *reinterpret_cast<const u32x4*>((const bf16_t*)p.wp + ((long)t * p.Mpad) * 64 + ch) : u32x4{0u, 0u, 0u, 0u};
+    }
+  // this lane's halo pixel of each of its wave's blocks (block = wave + 4 i): element offset inside a slice, -1 = padding
+  int xo[kFaninMaxNT];
+#pragma unroll
+  for (int i = 0; i < kFaninMaxNT; ++i) {
+    const int q = (wave + 4 * i) * 16 + l15;
+    const int ih = q / IW, iw = q - ih * IW;
+    const int gh = oh0 - p.pad_t + ih, gw = ow0 - p.pad_l + iw;
+    xo[i] = (q < NPX && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) ? (gh * p.W + gw) * p.ldx + 8 * lg : -1;
+  }
+  u32x4 xv[kFaninMaxNT][NK];
+  auto fetch = [&](int s) {                                         // s: input slice (any integer; outside the volume = zeros)
+    const bool in = s >= 0 && s < p.D;                              // uniform
+    const bf16_t* xs = xb + (long)(in ? s : 0) * p.H * p.W * p.ldx;
+#pragma unroll
+    for (int i = 0; i < kFaninMaxNT; ++i)
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks)
+        xv[i][ks] = (in && wave + 4 * i < nblk && xo[i] >= 0 && ks * 32 + 8 * lg < p.Cin) ? *reinterpret_cast<const u32x4*>(xs + xo[i] + ks * 32)
+                                                                                          : u32x4{0u, 0u, 0u, 0u};
+  };
+  const int r = tid >> 5, c = tid & 31;                             // this thread's output pixel of the tile
+  const bool live = oh0 + r < p.Ho && ow0 + c < p.Wo;
+  const float bias = p.bias ? p.bias[0] : 0.f;
+  auto store = [&](int z, float v) {
+    v += bias;
+    if (p.act == 1) v = fmaxf(v, 0.f);
+    else if (p.act == 2) v = 1.f / (1.f + __expf(-v));
+    if (live) ((bf16_t*)p.y)[((((long)b * p.Do + z) * p.Ho + oh0 + r) * p.Wo + ow0 + c) * p.ldy] = f2bf(v);
+  };
+
+  float run1 = 0.f, run2 = 0.f;                                     // sums of output slices s + pad_d - 1, s + pad_d - 2 so far
+  const int s_begin = z0 - p.pad_d, ns = nz + KD - 1;
+  fetch(s_begin);
+  for (int si = 0; si < ns; ++si) {
+    const int s = s_begin + si;
+    __syncthreads();                                                // the sums of the previous slice have been taken
+#pragma unroll
+    for (int i = 0; i < kFaninMaxNT; ++i) {
+      if (wave + 4 * i < nblk) {                                    // uniform
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+          Mma<bf16_t>::run(acc[0], af[0][ks], xv[i][ks]);
+          Mma<bf16_t>::run(acc[1], af[1][ks], xv[i][ks]);
+        }
+        const int q = (wave + 4 * i) * 16 + l15;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int t = mt * 16 + 4 * lg + e;
+            if (t < Tn) P[t * p.pitch + q] = acc[mt][e];
+          }
+      }
+    }
+    __syncthreads();
+    if (si + 1 < ns) fetch(s + 1);                                  // in flight behind the sums
+    float S[KD];
+#pragma unroll
+    for (int k = 0; k < KD; ++k) {
+      float a = 0.f;
+      const float* Pk = P + (k * T2) * p.pitch + r * IW + c;
+      for (int khi = 0; khi < p.kh; ++khi)
+        for (int kwi = 0; kwi < p.kw; ++kwi) a += Pk[(khi * p.kw + kwi) * p.pitch + khi * IW + kwi];
+      S[k] = a;
+    }
+    if constexpr (KD == 1) {
+      store(s + p.pad_d, S[0]);
+    } else {
+      const int zf = s + p.pad_d - 2;                               // the slice whose last depth tap this was
+      if (zf >= z0 && zf < z0 + nz) store(zf, run2 + S[2]);
+      run2 = run1 + S[1];
+      run1 = S[0];
+    }
+  }
+}
+
+inline bool fanin_ok(int Cin, int Cout, int kh, int kw, int stride, int dil, int kd, int sd, int ldx, const void* x) {
+  if (!(Cout == 1 && Cin % 8 == 0 && Cin >= 16 && stride == 1 && dil == 1 && sd == 1 && kh * kw * kd <= 32 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0)) return false;
+  if (kd == 3) { if (Cin > 32) return false; } else if (kd != 1 || Cin > 64) return false;
+  return (8 + kh - 1) * (32 + kw - 1) <= kFaninMaxNT * 64;
+}
+
+inline int launch_fanin(FaninArgs a, int kd, hipStream_t s) {
+  const int npx = (8 + a.kh - 1) * (32 + a.kw - 1);
+  a.npxp = (npx + 15) & ~15;
+  a.pitch = a.npxp + 4;
+  const size_t lds = (size_t)a.kh * a.kw * kd * a.pitch * sizeof(float);
+  if (lds > 64 * 1024) return 1;                                    // (the caller takes another kernel)
+  int dpw = kd == 1 ? 1 : 12;
+  if (dpw > a.Do) dpw = a.Do;
+  const long tiles = (long)sdhip_cdiv(a.Ho, 8) * sdhip_cdiv(a.Wo, 32) * a.B;
+  while (dpw > 4 && tiles * sdhip_cdiv(a.Do, dpw) < 1024) --dpw;
+  a.dpw = dpw; a.zsegs = sdhip_cdiv(a.Do, dpw);
+  if ((long)a.B * a.zsegs > 65535) return 1;
+  dim3 grid(sdhip_cdiv(a.Ho, 8) * sdhip_cdiv(a.Wo, 32), a.B * a.zsegs);
+  if (kd == 3) hipLaunchKernelGGL((conv_fanin_kernel<3, 1>), grid, dim3(256), lds, s, a);
+  else if (a.Cin <= 32) hipLaunchKernelGGL((conv_fanin_kernel<1, 1>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((conv_fanin_kernel<1, 2>), grid, dim3(256), lds, s, a);
+  SDHIP_LAUNCH_CHECK();
+  return SDHIP_OK;
+}
+
 }  // namespace

@@ -253,6 +253,32 @@ def test_fanout_conv_one_input_channel(k, dil, B, co, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,B,ci,H,W,act", [(5, 2, 64, 100, 450, 0), (3, 4, 32, 33, 47, 1), (5, 2, 24, 16, 32, 2), (1, 2, 64, 40, 70, 0), (3, 1, 16, 8, 31, 0)])
+def test_fanin_conv_one_output_map(k, B, ci, H, W, act):
+    """conv_fanin_kernel (16..64 input channels -> ONE output map: taps as the MFMA rows, P[tap][halo pixel] through LDS, a
+    fixed-order sum over taps; the single-map heads of the 2-D networks) against an f32 convolution of the same bf16-rounded
+    operands, with bias and activation; two launches agree bit for bit."""
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    g = torch.Generator().manual_seed(k * 31 + ci)
+    x = torch.randn(B, ci, H, W, generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    xv, ldx = ops.nhwc_view(x)
+    w = (torch.randn(1, ci, k, k, generator=g) * 0.1).cuda()
+    bias = torch.full((1,), 0.25, device="cuda")
+    wp = ops.packed_weight(w, 'conv', 'fwd', torch.bfloat16)
+    pad = k // 2
+    ys = []
+    for _ in range(2):
+        y, ldy = ops.alloc_nhwc(B, 1, H, W, torch.bfloat16, "cuda")
+        ops._conv_launch(xv, ldx, wp, y, ldy, bias, None, None, None, B, H, W, ci, H, W, 1, k, k, 1, 1, pad, pad, False, 1, act, False)
+        ys.append(y)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float().cpu(), w.bfloat16().float().cpu(), bias.cpu(), padding=pad)
+    ref = torch.relu(ref) if act == 1 else (torch.sigmoid(ref) if act == 2 else ref)
+    assert torch.equal(ys[0], ys[1])
+    assert (ys[0].float().cpu() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,ci,co", [(5, 64, 64), (5, 32, 32), (3, 32, 64)])
 def test_band_full_size_translation_equivariance(k, ci, co):
     """Size-independent property at the benchmark's full size (8 x 256 x 512): shifting the input by one tile (16 rows, 32

@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--model", default="minidsnetExt", choices=["minidsnetExt", "psmnet", "dsnet", "dsnetnoCorr"],
+    ap.add_argument("--model", default="minidsnetExt", choices=["minidsnetExt", "psmnet", "dsnet", "dsnetnoCorr", "minidsnetExt_cfg5"],
                     help="psmnet = BASELINE config 3 (PSMNet(192), build-defined loss: mean L1 of the three predictions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -318,8 +318,10 @@ def main():
         loss_fn = lambda outs, seg, disp: _ops.mean_l1_loss(outs, disp[:, 0])
     elif a.model in ("dsnet", "dsnetnoCorr"):     # log-softmax heads: the same CE + Lovasz + L1 composition applies to them
         loss_fn = lambda outs, seg, disp: _ops.train_loss(outs[0], outs[1], outs[2], seg, disp, True)
+    elif a.model == "minidsnetExt_cfg5":          # the cityscapes rules: void pixels, disp > 0 mask
+        loss_fn = lambda outs, seg, disp: _ops.train_loss(outs[0], outs[1], outs[2], seg, disp, True, True, True)
     step = TrainStep(model, dtype=dtype, use_graph=not a.no_graph, world_size=world, process_group=pg, loss_fn=loss_fn)
-    batch = synthetic_batch(a.batch, a.height, a.width, seed=1234 + rank)
+    batch = synthetic_batch(a.batch, a.height, a.width, labels=19 if a.model == "minidsnetExt_cfg5" else 2, seed=1234 + rank)
     for _ in range(a.warmup):
         loss = step(*batch)
 
@@ -349,6 +351,10 @@ def main():
                                        if a.model == "minidsnetExt" else
                                        "dsnet (PyTorch port of baseline_SDnet_small_fixed, 2-D corr) train step fwd+loss+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s"
                                        if a.model == "dsnet" else
+                                       "minidsnetExt(aspp=2, hanet=1, 19 classes; BASELINE config 5) train step fwd+loss(cityscapes rules)+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s"
+                                       if a.model == "minidsnetExt_cfg5" else
+                                       "dsnetnoCorr (baseline_SDnet_small) train step fwd+loss+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s"
+                                       if a.model == "dsnetnoCorr" else
                                        "PSMNet(192) stacked hourglass train step fwd+loss(mean L1 x3)+bwd+Adam, %dx%d (WxH), batch %d per GPU, %s")
                                       % (a.width, a.height, a.batch, "hipGraph" if step.use_graph else "eager"),
                           "global_batch": a.batch * world, "parallelism": "dp%d" % world,

@@ -1,36 +1,166 @@
 // Lovasz-softmax loss (util/lovasz_losses.py:153-199 with classes='present', per_image=False, applied to
 // softmax(log_softmax(logits)) = softmax(logits) and labels = argmax(one-hot), losses/multiLosses.py:70-72), forward
-// value and gradient w.r.t. the logits in one call.  HBM bound: per class one descending radix sort of (|fg - p|, index)
-// over all B*H*W pixels (rocPRIM device primitives), an inclusive scan of the sorted foreground flags, and two
-// elementwise passes.  The Jaccard gradient is a constant w.r.t. the errors (as in the reference, which detaches it),
-// so d loss / d p_c[i] = -sign(fg - p) * lovasz_grad(fg_sorted)[rank(i)].
+// value and gradient w.r.t. the logits in one call.  HBM bound: ONE segmented descending sort of (|fg - p|, index) — a
+// segment per class, all B*H*W pixels each — a prefix count of the sorted foreground flags, and two elementwise passes.
+// The Jaccard gradient is a constant w.r.t. the errors (as in the reference, which detaches it), so
+// d loss / d p_c[i] = -sign(fg - p) * lovasz_grad(fg_sorted)[rank(i)].
 // ignore=<void label> (flatten_probas :202-216; cityscapes: losses/multiLosses.py:19-21 drops the 20th one-hot channel and
-// passes ignore=19): a pixel whose target row has no positive entry is VOID.  Void pixels get the key -1 (every real error
-// is >= 0), so the descending sort parks them behind the nvalid real entries; the Jaccard walk stops at nvalid and they
-// receive no gradient — the same as removing them from the flattened arrays.
+// passes ignore=19): a pixel whose target row has no positive entry is VOID.  Void pixels get the largest key, so the sort
+// parks them behind the nvalid real entries; the Jaccard walk stops at nvalid and they receive no gradient — the same as
+// removing them from the flattened arrays.
 // ignore=None (roses / garden, losses/multiLosses.py:11-17): nothing is void — the label of an all-zero row is argmax = class 0
 // and the pixel counts like any other.  `ignore_void` selects between the two rules.
+//
+// The sort (the step's only torch.sort): a least-significant-digit radix sort written for this use, every
+// class in the same launches (grid.y = class) — 12 launches per loss where a library sort per class took 26 x C (494 of
+// a 19-class step's 1595 kernels, 5.0 ms), and kernels only (the library's one-sweep path clears its histograms with
+// memset nodes, which hipGraph replay on ROCm 7.2 does not honour reliably).
+//   key    0x3F800000 - bits(err), err in [0, 1]: ascending key = descending error; void = 0x3F800001.  30 significant bits:
+//          four passes of 8 bits.
+//   unit   a WAVE owns 2048 consecutive elements (32 rounds of 64) and a column of the digit table [class][digit][column]:
+//          sort_hist counts, sort_scan turns the table into exclusive offsets (digit-major, then column: a stable order),
+//          sort_scatter ranks each round's lanes among their equal-digit peers (8 ballots -> peer mask -> popcount of the
+//          lanes below) and adds the column's running offset.  No barrier inside the round loop, nothing shared between waves:
+//          the result is the same on every run.
 #include "sdhip_common.h"
-#include <cstring>
-#include <string.h>
-using std::memset;
-#include <rocprim/rocprim.hpp>
 
 namespace {
 
-// rocPRIM sorts up to 1 Mi keys with its merge sort and larger inputs with the one-sweep radix sort, which clears its
-// histograms with hipMemsetAsync — memset nodes once the step is captured, and those are not reliable under hipGraph
-// replay on ROCm 7.2 (sdhip_common.h, sdhip_zero_async).  The merge path launches kernels only: it is used at every size.
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t)1 << 40>;
+constexpr unsigned int kKeyOne = 0x3F800000u;       // key of err = 0 is kKeyOne, of err = 1 is 0
+constexpr unsigned int kKeyVoid = 0x3F800001u;
+constexpr int kSortKPW = 2048;                       // elements per wave
+constexpr int kSortRounds = kSortKPW / 64;
+constexpr int kChunk = 4096;                         // sorted elements per workgroup of the Jaccard walk
 
-struct FgFlag {
-  __device__ __host__ unsigned int operator()(unsigned int v) const { return v >> 31; }
-};
+__device__ __forceinline__ unsigned int wave_incl_scan(unsigned int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned int u = __shfl_up(v, d, 64);
+    if (lane >= d) v += u;
+  }
+  return v;
+}
 
-// keys[c][i] = |fg - p_c|, vals[c][i] = i | fg << 31, counts[c] += fg
+// bh[class][digit][column] = number of elements of the column's 2048 whose digit (bits shift .. shift+7 of the key) is `digit`
+__global__ __launch_bounds__(256) void sort_hist_kernel(const unsigned int* __restrict__ keys, unsigned int* __restrict__ bh,
+                                                        long npix, int cols, int shift) {
+  __shared__ unsigned int h[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.y;
+  const int col = blockIdx.x * 4 + wave;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h[wave][lane * 4 + j] = 0u;
+  __syncthreads();
+  if (col < cols) {
+    const unsigned int* k = keys + (long)c * npix;
+    const long base = (long)col * kSortKPW;
+    for (int r = 0; r < kSortRounds; ++r) {
+      const long i = base + r * 64 + lane;
+      if (i < npix) atomicAdd(&h[wave][(k[i] >> shift) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  if (col < cols) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int d = lane * 4 + j;
+      bh[((long)c * 256 + d) * cols + col] = h[wave][d];
+    }
+  }
+}
+
+// per class (blockIdx.x): the table's 256 x cols counts -> exclusive prefix in (digit, column) order.  16 waves, 16 digits each.
+__global__ __launch_bounds__(1024) void sort_scan_kernel(unsigned int* __restrict__ bh, int cols) {
+  __shared__ unsigned int tot[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int* t = bh + (long)blockIdx.x * 256 * cols;
+  for (int j = 0; j < 16; ++j) {
+    const int d = wave * 16 + j;
+    unsigned int sacc = 0u;
+    for (int i = lane; i < cols; i += 64) sacc += t[(long)d * cols + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+    if (lane == 0) tot[d] = sacc;
+  }
+  __syncthreads();
+  if (wave == 0) {                                   // exclusive scan of the 256 digit totals (4 per lane)
+    unsigned int v[4], sum = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = tot[lane * 4 + j]; sum += v[j]; }
+    unsigned int run = wave_incl_scan(sum, lane) - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { tot[lane * 4 + j] = run; run += v[j]; }
+  }
+  __syncthreads();
+  for (int j = 0; j < 16; ++j) {
+    const int d = wave * 16 + j;
+    unsigned int carry = tot[d];
+    for (int i0 = 0; i0 < cols; i0 += 64) {
+      const int i = i0 + lane;
+      const unsigned int v = i < cols ? t[(long)d * cols + i] : 0u;
+      const unsigned int inc = wave_incl_scan(v, lane);
+      if (i < cols) t[(long)d * cols + i] = carry + inc - v;
+      carry += __shfl(inc, 63, 64);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const unsigned int* __restrict__ kin, const unsigned int* __restrict__ vin,
+                                                           unsigned int* __restrict__ kout, unsigned int* __restrict__ vout,
+                                                           const unsigned int* __restrict__ bh, long npix, int cols, int shift) {
+  __shared__ unsigned int off[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.y;
+  const int col = blockIdx.x * 4 + wave;
+  if (col >= cols) return;                           // (whole waves; no workgroup barrier below)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int d = lane * 4 + j;
+    off[wave][d] = bh[((long)c * 256 + d) * cols + col];
+  }
+  const long seg = (long)c * npix, base = (long)col * kSortKPW;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int r = 0; r < kSortRounds; ++r) {
+    const long i = base + r * 64 + lane;
+    const bool valid = i < npix;
+    const unsigned int k = valid ? kin[seg + i] : 0u, v = valid ? vin[seg + i] : 0u;
+    const unsigned int d = (k >> shift) & 255u;
+    unsigned long long peers = __ballot(valid);      // lanes of this round with the same digit
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long m = __ballot(valid && bit);
+      peers &= bit ? m : ~m;
+    }
+    const unsigned int rank = (unsigned int)__popcll(peers & below), cnt = (unsigned int)__popcll(peers);
+    volatile unsigned int* const o = &off[wave][d];  // (every lane reads before the group's last lane writes: one wave, in order)
+    const unsigned int pos = *o + rank;
+    if (valid && rank + 1u == cnt) *o = pos + 1u;
+    if (valid) { kout[seg + pos] = k; vout[seg + pos] = v; }
+  }
+}
+
+// foreground elements of every chunk of kChunk sorted positions: bfg[class][chunk]
+__global__ __launch_bounds__(256) void lovasz_fgcount_kernel(const unsigned int* __restrict__ vals_sorted, unsigned int* __restrict__ bfg,
+                                                             long npix, int nchunk) {
+  __shared__ unsigned int sh[4];
+  const int c = blockIdx.y;
+  const long i0 = (long)blockIdx.x * kChunk;
+  const unsigned int* vs = vals_sorted + (long)c * npix;
+  unsigned int n = 0u;
+  for (int j = 0; j < kChunk / 256; ++j) {
+    const long i = i0 + j * 256 + threadIdx.x;
+    if (i < npix) n += vs[i] >> 31;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) bfg[(long)c * nchunk + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// keys[c][i] = sort key of |fg - p_c| (see above), vals[c][i] = i | fg << 31, counts[c] += fg
 template <typename T>
 __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ t, int ldt,
-                                                            float* __restrict__ keys, unsigned int* __restrict__ vals,
+                                                            unsigned int* __restrict__ keys, unsigned int* __restrict__ vals,
                                                             unsigned int* __restrict__ counts, long npix, int C, int ignore_void) {
   // per-class pixel counts: LDS histogram per workgroup, one global atomic per class per workgroup (a global atomic per
   // pixel on C addresses serialises: ~10 ms for 1M pixels)
@@ -50,7 +180,7 @@ __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict_
     }
     if (ignore_void && !(tbest > 0.f)) {   // void pixel
       for (int c = 0; c < C; ++c) {
-        keys[(long)c * npix + p] = -1.f;
+        keys[(long)c * npix + p] = kKeyVoid;
         vals[(long)c * npix + p] = (unsigned int)p;
       }
       atomicAdd(&nvoid, 1u);
@@ -62,7 +192,7 @@ __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict_
     for (int c = 0; c < C; ++c) {
       const float pc = __expf(Elem<T>::ld(yp + c) - mx) * inv;
       const unsigned int fg = label == c ? 1u : 0u;
-      keys[(long)c * npix + p] = fabsf((float)fg - pc);
+      keys[(long)c * npix + p] = kKeyOne - __float_as_uint(fminf(fabsf((float)fg - pc), 1.f));
       vals[(long)c * npix + p] = (unsigned int)p | (fg << 31);
     }
     if (C <= 64) atomicAdd(hist + label, 1u); else atomicAdd(counts + label, 1u);
@@ -72,31 +202,62 @@ __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict_
   if (threadIdx.x == 0 && nvoid) atomicAdd(counts + C, nvoid);   // counts[C] = number of void pixels
 }
 
-// per class (blockIdx.y): g_i = jaccard(i) - jaccard(i-1) over the sorted order; loss_c += err_i * g_i; gerr[c][orig] = g_i
-__global__ __launch_bounds__(256) void lovasz_grad_kernel(const float* __restrict__ keys_sorted, const unsigned int* __restrict__ vals_sorted,
-                                                          const unsigned int* __restrict__ cum, const unsigned int* __restrict__ counts,
-                                                          float* __restrict__ gerr, double* __restrict__ lossc, long npix, int C) {
+// per class (blockIdx.y) and chunk of kChunk sorted positions (blockIdx.x): cum_i = foreground elements among positions
+// 0..i (the chunks before this one from bfg, inside the chunk a scan: 16 consecutive positions per thread), g_i = jaccard(i) -
+// jaccard(i-1); loss_c += err_i * g_i; gerr[c][orig] = g_i
+__global__ __launch_bounds__(256) void lovasz_grad_kernel(const unsigned int* __restrict__ keys_sorted, const unsigned int* __restrict__ vals_sorted,
+                                                          const unsigned int* __restrict__ bfg, const unsigned int* __restrict__ counts,
+                                                          float* __restrict__ gerr, double* __restrict__ lossc, long npix, int C, int nchunk) {
+  __shared__ unsigned int shu[4];
   __shared__ float sh[4];
-  const int c = blockIdx.y;
+  const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long nvalid = npix - (long)counts[C];
   const double gts = (double)counts[c];
-  const float* ks = keys_sorted + (long)c * npix;
+  if (!(gts > 0.) || (long)blockIdx.x * kChunk >= nvalid) return;          // class absent / only void entries here (uniform)
+  const unsigned int* ks = keys_sorted + (long)c * npix;
   const unsigned int* vs = vals_sorted + (long)c * npix;
-  const unsigned int* cu = cum + (long)c * npix;
+  // foreground elements in the chunks before this one
+  unsigned int before = 0u;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) before += bfg[(long)c * nchunk + j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (lane == 0) shu[wave] = before;
+  __syncthreads();
+  before = shu[0] + shu[1] + shu[2] + shu[3];
+  __syncthreads();
+  // this thread's 16 consecutive positions
+  constexpr int PT = kChunk / 256;
+  const long i0 = (long)blockIdx.x * kChunk + (long)threadIdx.x * PT;
+  unsigned int v[PT], k[PT], mine = 0u;
+#pragma unroll
+  for (int j = 0; j < PT; ++j) {
+    const long i = i0 + j;
+    v[j] = i < nvalid ? vs[i] : 0u;
+    k[j] = i < nvalid ? ks[i] : kKeyOne;
+    mine += v[j] >> 31;
+  }
+  const unsigned int inc = wave_incl_scan(mine, lane);
+  if (lane == 63) shu[wave] = inc;
+  __syncthreads();
+  unsigned int cum = before + inc - mine;                                  // foreground elements before position i0
+  for (int w = 0; w < wave; ++w) cum += shu[w];
   float part = 0.f;
-  if (gts > 0.) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvalid; i += (long)gridDim.x * 256) {
-      const double ci = (double)cu[i];
+#pragma unroll
+  for (int j = 0; j < PT; ++j) {
+    const long i = i0 + j;
+    const double cp = (double)cum;                                         // cum_{i-1}
+    cum += v[j] >> 31;
+    if (i < nvalid) {
+      const double ci = (double)cum;
       const double jac = 1.0 - (gts - ci) / (gts + (double)(i + 1) - ci);
-      double prev = 0.0;
-      if (i > 0) { const double cp = (double)cu[i - 1]; prev = 1.0 - (gts - cp) / (gts + (double)i - cp); }
+      const double prev = i > 0 ? 1.0 - (gts - cp) / (gts + (double)i - cp) : 0.0;
       const float gi = (float)(jac - prev);
-      part = fmaf(ks[i], gi, part);
-      gerr[(long)c * npix + (vs[i] & 0x7fffffffu)] = gi;
+      part = fmaf(__uint_as_float(kKeyOne - k[j]), gi, part);
+      gerr[(long)c * npix + (v[j] & 0x7fffffffu)] = gi;
     }
   }
   part = wave_sum(part);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+  if (lane == 0) sh[wave] = part;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(lossc + c, (double)(sh[0] + sh[1] + sh[2] + sh[3]));
 }
@@ -151,29 +312,26 @@ __global__ __launch_bounds__(256) void lovasz_backward_kernel(const T* __restric
 }
 
 struct Layout {
-  size_t keys_in, keys_out, vals_in, vals_out, cum, gerr, counts, lossc, temp, temp_bytes, total;
+  size_t keys_a, keys_b, vals_a, vals_b, gerr, counts, lossc, bfg, table, total;
+  int cols, nchunk;
 };
 
 Layout layout(long npix, int C) {
   Layout L;
   const size_t n = (size_t)npix * C;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  L.cols = (int)((npix + kSortKPW - 1) / kSortKPW);
+  L.nchunk = (int)((npix + kChunk - 1) / kChunk);
   size_t off = 0;
-  L.keys_in = off; off = al(off + n * 4);
-  L.keys_out = off; off = al(off + n * 4);
-  L.vals_in = off; off = al(off + n * 4);
-  L.vals_out = off; off = al(off + n * 4);
-  L.cum = off; off = al(off + n * 4);
+  L.keys_a = off; off = al(off + n * 4);
+  L.keys_b = off; off = al(off + n * 4);
+  L.vals_a = off; off = al(off + n * 4);
+  L.vals_b = off; off = al(off + n * 4);
   L.gerr = off; off = al(off + n * 4);
   L.counts = off; off = al(off + (size_t)(C + 1) * 4);
   L.lossc = off; off = al(off + (size_t)C * 8);
-  size_t t1 = 0, t2 = 0;
-  (void)rocprim::radix_sort_pairs_desc<SortConfig>(nullptr, t1, (const float*)nullptr, (float*)nullptr, (const unsigned int*)nullptr,
-                                 (unsigned int*)nullptr, (size_t)npix);
-  auto it = rocprim::make_transform_iterator((const unsigned int*)nullptr, FgFlag());
-  (void)rocprim::inclusive_scan(nullptr, t2, it, (unsigned int*)nullptr, (size_t)npix, rocprim::plus<unsigned int>());
-  L.temp_bytes = t1 > t2 ? t1 : t2;
-  L.temp = off; off = al(off + L.temp_bytes);
+  L.bfg = off; off = al(off + (size_t)C * L.nchunk * 4);
+  L.table = off; off = al(off + (size_t)C * 256 * L.cols * 4);
   L.total = off;
   return L;
 }
@@ -212,30 +370,33 @@ extern "C" int sdhip_lovasz_softmax(const void* logits, int ldy, const float* ta
   SDHIP_CHECK_ARG((size_t)workspace_bytes >= L.total, "lovasz_softmax: workspace too small (%ld < %zu)", workspace_bytes, L.total);
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
-  float* keys_in = (float*)(ws + L.keys_in); float* keys_out = (float*)(ws + L.keys_out);
-  unsigned int* vals_in = (unsigned int*)(ws + L.vals_in); unsigned int* vals_out = (unsigned int*)(ws + L.vals_out);
-  unsigned int* cum = (unsigned int*)(ws + L.cum);
+  unsigned int* keys_a = (unsigned int*)(ws + L.keys_a); unsigned int* keys_b = (unsigned int*)(ws + L.keys_b);
+  unsigned int* vals_a = (unsigned int*)(ws + L.vals_a); unsigned int* vals_b = (unsigned int*)(ws + L.vals_b);
   float* gerr = (float*)(ws + L.gerr);
   unsigned int* counts = (unsigned int*)(ws + L.counts);
   double* lossc = (double*)(ws + L.lossc);
+  unsigned int* bfg = (unsigned int*)(ws + L.bfg);
+  unsigned int* table = (unsigned int*)(ws + L.table);
+  SDHIP_CHECK_ARG(C <= 65535, "lovasz_softmax: more than 65535 classes");
   // (a kernel, not hipMemsetAsync: the step is replayed from a hipGraph, and everything in it is kept to kernel nodes)
-  if (sdhip_zero_async(ws + L.counts, L.temp - L.counts, s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "lovasz_softmax: clearing the counters failed");
+  if (sdhip_zero_async(ws + L.counts, L.bfg - L.counts, s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "lovasz_softmax: clearing the counters failed");
   if (dtype == SDHIP_F32)
-    hipLaunchKernelGGL(lovasz_errors_kernel<float>, grid_for(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, keys_in, vals_in, counts, npix, C, ignore_void);
+    hipLaunchKernelGGL(lovasz_errors_kernel<float>, grid_for(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, keys_a, vals_a, counts, npix, C, ignore_void);
   else
-    hipLaunchKernelGGL(lovasz_errors_kernel<bf16_t>, grid_for(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, keys_in, vals_in, counts, npix, C, ignore_void);
-  for (int c = 0; c < C; ++c) {
-    size_t tb = L.temp_bytes;
-    const size_t o = (size_t)c * npix;
-    if (rocprim::radix_sort_pairs_desc<SortConfig>(ws + L.temp, tb, keys_in + o, keys_out + o, vals_in + o, vals_out + o, (size_t)npix, 0, 32, s) != hipSuccess)
-      SDHIP_FAIL(SDHIP_ERR_LAUNCH, "lovasz_softmax: radix sort failed");
-    tb = L.temp_bytes;
-    auto it = rocprim::make_transform_iterator((const unsigned int*)(vals_out + o), FgFlag());
-    if (rocprim::inclusive_scan(ws + L.temp, tb, it, cum + o, (size_t)npix, rocprim::plus<unsigned int>(), s) != hipSuccess)
-      SDHIP_FAIL(SDHIP_ERR_LAUNCH, "lovasz_softmax: scan failed");
+    hipLaunchKernelGGL(lovasz_errors_kernel<bf16_t>, grid_for(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, keys_a, vals_a, counts, npix, C, ignore_void);
+  // four stable passes over bits 0-7, 8-15, 16-23, 24-31 (keys < 2^30); a -> b -> a -> b -> a: the sorted arrays end in `a`
+  const dim3 gs((unsigned)((L.cols + 3) / 4), (unsigned)C);
+  for (int pass = 0; pass < 4; ++pass) {
+    const unsigned int* kin = (pass & 1) ? keys_b : keys_a; const unsigned int* vin = (pass & 1) ? vals_b : vals_a;
+    unsigned int* kout = (pass & 1) ? keys_a : keys_b; unsigned int* vout = (pass & 1) ? vals_a : vals_b;
+    hipLaunchKernelGGL(sort_hist_kernel, gs, dim3(256), 0, s, kin, table, npix, L.cols, 8 * pass);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)C), dim3(1024), 0, s, table, L.cols);
+    hipLaunchKernelGGL(sort_scatter_kernel, gs, dim3(256), 0, s, kin, vin, kout, vout, (const unsigned int*)table, npix, L.cols, 8 * pass);
   }
-  dim3 g2 = grid_for(npix); g2.y = C;
-  hipLaunchKernelGGL(lovasz_grad_kernel, g2, dim3(256), 0, s, keys_out, vals_out, cum, counts, gerr, lossc, npix, C);
+  const dim3 gc((unsigned)L.nchunk, (unsigned)C);
+  hipLaunchKernelGGL(lovasz_fgcount_kernel, gc, dim3(256), 0, s, (const unsigned int*)vals_a, bfg, npix, L.nchunk);
+  hipLaunchKernelGGL(lovasz_grad_kernel, gc, dim3(256), 0, s, (const unsigned int*)keys_a, (const unsigned int*)vals_a, (const unsigned int*)bfg,
+                     (const unsigned int*)counts, gerr, lossc, npix, C, L.nchunk);
   if (dtype == SDHIP_F32)
     hipLaunchKernelGGL(lovasz_backward_kernel<float>, grid_stream(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, gerr, counts, lossc, (float*)grad, ldg, loss, npix, C, weight, ignore_void);
   else

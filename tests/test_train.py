@@ -130,6 +130,36 @@ def test_lovasz_single_class_present():
     assert float(((g1.grad + g2.grad).cpu() - r.grad).abs().max()) < 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W,void", [(1, 19, 50, 83, True), (2, 5, 64, 100, False), (8, 2, 256, 512, False), (2, 19, 256, 512, True)])
+def test_lovasz_segmented_sort_sizes(B, C, H, W, void):
+    """The hand-written segmented radix sort behind sdhip_lovasz_softmax (lovasz.hip: a wave owns 2048 elements, four stable
+    8-bit passes, every class in the same launches): sizes that are no multiple of a wave's share, 19 classes with void
+    pixels, and the benchmark's full size, against the restated reference formula run on the same device (torch.sort);
+    two calls agree bit for bit (nothing in the sort depends on timing)."""
+    import torch.nn.functional as F
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    seg = torch.randn(B, C, H, W, generator=g) * 2
+    lab = torch.randint(0, C + (1 if void else 0), (B, H, W), generator=g)
+    seg_t = F.one_hot(lab, C + (1 if void else 0)).permute(0, 3, 1, 2).float()[:, :C].contiguous()   # label C = void: an all-zero row
+    zero = torch.zeros(B, 1, H, W)
+    from oracle.losses_ref import train_loss_ref
+    st = seg_t.cuda()
+    r1 = seg.clone().cuda().requires_grad_(True); r = seg.clone().cuda().requires_grad_(True)
+    want = train_loss_ref(r1, zero.cuda(), r, st, zero.cuda(), True, void, void)
+    want.backward()
+    outs = []
+    for _ in range(2):
+        g1 = seg.cuda().requires_grad_(True); g2 = seg.cuda().requires_grad_(True)
+        got = ops.train_loss(g1, zero.cuda().requires_grad_(True), g2, st, zero.cuda(), True, void, void)
+        got.backward()
+        outs.append((got.detach().clone(), g2.grad.clone(), g1.grad.clone()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert abs(float(outs[0][0]) - float(want)) < 2e-5 * max(1.0, abs(float(want))), (float(outs[0][0]), float(want))
+    assert float((outs[0][1] - r.grad).abs().max()) < 1e-7 + 1e-4 * float(r.grad.abs().max())
+
+
 def _aspp_model():
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N
     torch.manual_seed(0)

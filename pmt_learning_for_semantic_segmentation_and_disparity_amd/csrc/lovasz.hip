@@ -42,7 +42,7 @@ __device__ __forceinline__ unsigned int wave_incl_scan(unsigned int v, int lane)
 }
 
 // bh[class][digit][column] = number of elements of the column's 2048 whose digit (bits shift .. shift+7 of the key) is `digit`
-__global__ __launch_bounds__(256) void sort_hist_kernel(const unsigned int* __restrict__ keys, unsigned int* __restrict__ bh,
+__global__ __launch_bounds__(256) void sort_hist_kernel(const uint2* __restrict__ kv, unsigned int* __restrict__ bh,
                                                         long npix, int cols, int shift) {
   __shared__ unsigned int h[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.y;
@@ -51,11 +51,20 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const unsigned int* __re
   for (int j = 0; j < 4; ++j) h[wave][lane * 4 + j] = 0u;
   __syncthreads();
   if (col < cols) {
-    const unsigned int* k = keys + (long)c * npix;
+    const uint2* k = kv + (long)c * npix;
     const long base = (long)col * kSortKPW;
-    for (int r = 0; r < kSortRounds; ++r) {
-      const long i = base + r * 64 + lane;
-      if (i < npix) atomicAdd(&h[wave][(k[i] >> shift) & 255u], 1u);
+    for (int r0 = 0; r0 < kSortRounds; r0 += 8) {     // eight loads in flight
+      unsigned int kk[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const long i = base + (r0 + j) * 64 + lane;
+        kk[j] = i < npix ? k[i].x : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const long i = base + (r0 + j) * 64 + lane;
+        if (i < npix) atomicAdd(&h[wave][(kk[j] >> shift) & 255u], 1u);
+      }
     }
   }
   __syncthreads();
@@ -68,87 +77,92 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const unsigned int* __re
   }
 }
 
-// per class (blockIdx.x): the table's 256 x cols counts -> exclusive prefix in (digit, column) order.  16 waves, 16 digits each.
-__global__ __launch_bounds__(1024) void sort_scan_kernel(unsigned int* __restrict__ bh, int cols) {
-  __shared__ unsigned int tot[256];
+// one wave per (class, digit) row of the table: the row's counts -> exclusive prefix over the columns (in place), the row's
+// total -> tot[class][digit].  (The prefix over the digits is 256 values: every scatter wave forms it itself.)
+__global__ __launch_bounds__(256) void sort_scan_kernel(unsigned int* __restrict__ bh, unsigned int* __restrict__ tot, int cols, int nrows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned int* t = bh + (long)blockIdx.x * 256 * cols;
-  for (int j = 0; j < 16; ++j) {
-    const int d = wave * 16 + j;
-    unsigned int sacc = 0u;
-    for (int i = lane; i < cols; i += 64) sacc += t[(long)d * cols + i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
-    if (lane == 0) tot[d] = sacc;
+  const int row = blockIdx.x * 4 + wave;              // class * 256 + digit
+  if (row >= nrows) return;
+  unsigned int* t = bh + (long)row * cols;
+  unsigned int carry = 0u;
+  for (int i0 = 0; i0 < cols; i0 += 64) {
+    const int i = i0 + lane;
+    const unsigned int v = i < cols ? t[i] : 0u;
+    const unsigned int inc = wave_incl_scan(v, lane);
+    if (i < cols) t[i] = carry + inc - v;
+    carry += __shfl(inc, 63, 64);
   }
-  __syncthreads();
-  if (wave == 0) {                                   // exclusive scan of the 256 digit totals (4 per lane)
-    unsigned int v[4], sum = 0u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] = tot[lane * 4 + j]; sum += v[j]; }
-    unsigned int run = wave_incl_scan(sum, lane) - sum;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { tot[lane * 4 + j] = run; run += v[j]; }
-  }
-  __syncthreads();
-  for (int j = 0; j < 16; ++j) {
-    const int d = wave * 16 + j;
-    unsigned int carry = tot[d];
-    for (int i0 = 0; i0 < cols; i0 += 64) {
-      const int i = i0 + lane;
-      const unsigned int v = i < cols ? t[(long)d * cols + i] : 0u;
-      const unsigned int inc = wave_incl_scan(v, lane);
-      if (i < cols) t[(long)d * cols + i] = carry + inc - v;
-      carry += __shfl(inc, 63, 64);
-    }
-  }
+  if (lane == 0) tot[row] = carry;
 }
 
-__global__ __launch_bounds__(256) void sort_scatter_kernel(const unsigned int* __restrict__ kin, const unsigned int* __restrict__ vin,
-                                                           unsigned int* __restrict__ kout, unsigned int* __restrict__ vout,
-                                                           const unsigned int* __restrict__ bh, long npix, int cols, int shift) {
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const uint2* __restrict__ kvin, uint2* __restrict__ kvout,
+                                                           const unsigned int* __restrict__ bh, const unsigned int* __restrict__ tot,
+                                                           long npix, int cols, int shift) {
   __shared__ unsigned int off[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.y;
   const int col = blockIdx.x * 4 + wave;
   if (col >= cols) return;                           // (whole waves; no workgroup barrier below)
+  {
+    // digit d starts at the sum of the totals of the digits below it, plus this column's share of the digit's row
+    unsigned int tv[4], sum = 0u;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int d = lane * 4 + j;
-    off[wave][d] = bh[((long)c * 256 + d) * cols + col];
+    for (int j = 0; j < 4; ++j) { tv[j] = tot[c * 256 + lane * 4 + j]; sum += tv[j]; }
+    unsigned int run = wave_incl_scan(sum, lane) - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int d = lane * 4 + j;
+      off[wave][d] = run + bh[((long)c * 256 + d) * cols + col];
+      run += tv[j];
+    }
   }
   const long seg = (long)c * npix, base = (long)col * kSortKPW;
   const unsigned long long below = (1ull << lane) - 1ull;
-  for (int r = 0; r < kSortRounds; ++r) {
-    const long i = base + r * 64 + lane;
-    const bool valid = i < npix;
-    const unsigned int k = valid ? kin[seg + i] : 0u, v = valid ? vin[seg + i] : 0u;
-    const unsigned int d = (k >> shift) & 255u;
-    unsigned long long peers = __ballot(valid);      // lanes of this round with the same digit
+  constexpr int G = 8;                               // rounds whose loads are in flight together
+  uint2 kb[2][G];
+  auto fetch = [&](int g, uint2 (&k)[G]) {
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const unsigned long long m = __ballot(valid && bit);
-      peers &= bit ? m : ~m;
+    for (int j = 0; j < G; ++j) {
+      const long i = base + (g * G + j) * 64 + lane;
+      k[j] = i < npix ? kvin[seg + i] : make_uint2(0u, 0u);
     }
-    const unsigned int rank = (unsigned int)__popcll(peers & below), cnt = (unsigned int)__popcll(peers);
-    volatile unsigned int* const o = &off[wave][d];  // (every lane reads before the group's last lane writes: one wave, in order)
-    const unsigned int pos = *o + rank;
-    if (valid && rank + 1u == cnt) *o = pos + 1u;
-    if (valid) { kout[seg + pos] = k; vout[seg + pos] = v; }
+  };
+  fetch(0, kb[0]);
+#pragma unroll
+  for (int g = 0; g < kSortRounds / G; ++g) {
+    if (g + 1 < kSortRounds / G) fetch(g + 1, kb[(g + 1) & 1]);
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const long i = base + (g * G + j) * 64 + lane;
+      const bool valid = i < npix;
+      const unsigned int k = kb[g & 1][j].x;
+      const unsigned int d = (k >> shift) & 255u;
+      unsigned long long peers = __ballot(valid);    // lanes of this round with the same digit
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+      }
+      const unsigned int rank = (unsigned int)__popcll(peers & below), cnt = (unsigned int)__popcll(peers);
+      volatile unsigned int* const o = &off[wave][d];  // (every lane reads before the group's last lane writes: one wave, in order)
+      const unsigned int pos = *o + rank;
+      if (valid && rank + 1u == cnt) *o = pos + 1u;
+      if (valid) kvout[seg + pos] = kb[g & 1][j];
+    }
   }
 }
 
 // foreground elements of every chunk of kChunk sorted positions: bfg[class][chunk]
-__global__ __launch_bounds__(256) void lovasz_fgcount_kernel(const unsigned int* __restrict__ vals_sorted, unsigned int* __restrict__ bfg,
+__global__ __launch_bounds__(256) void lovasz_fgcount_kernel(const uint2* __restrict__ kv_sorted, unsigned int* __restrict__ bfg,
                                                              long npix, int nchunk) {
   __shared__ unsigned int sh[4];
   const int c = blockIdx.y;
   const long i0 = (long)blockIdx.x * kChunk;
-  const unsigned int* vs = vals_sorted + (long)c * npix;
+  const uint2* vs = kv_sorted + (long)c * npix;
   unsigned int n = 0u;
   for (int j = 0; j < kChunk / 256; ++j) {
     const long i = i0 + j * 256 + threadIdx.x;
-    if (i < npix) n += vs[i] >> 31;
+    if (i < npix) n += vs[i].y >> 31;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
@@ -157,10 +171,10 @@ __global__ __launch_bounds__(256) void lovasz_fgcount_kernel(const unsigned int*
   if (threadIdx.x == 0) bfg[(long)c * nchunk + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// keys[c][i] = sort key of |fg - p_c| (see above), vals[c][i] = i | fg << 31, counts[c] += fg
+// kv[c][i] = (sort key of |fg - p_c| (see above), i | fg << 31), counts[c] += fg
 template <typename T>
 __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ t, int ldt,
-                                                            unsigned int* __restrict__ keys, unsigned int* __restrict__ vals,
+                                                            uint2* __restrict__ kv,
                                                             unsigned int* __restrict__ counts, long npix, int C, int ignore_void) {
   // per-class pixel counts: LDS histogram per workgroup, one global atomic per class per workgroup (a global atomic per
   // pixel on C addresses serialises: ~10 ms for 1M pixels)
@@ -180,8 +194,7 @@ __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict_
     }
     if (ignore_void && !(tbest > 0.f)) {   // void pixel
       for (int c = 0; c < C; ++c) {
-        keys[(long)c * npix + p] = kKeyVoid;
-        vals[(long)c * npix + p] = (unsigned int)p;
+        kv[(long)c * npix + p] = make_uint2(kKeyVoid, (unsigned int)p);
       }
       atomicAdd(&nvoid, 1u);
       continue;
@@ -192,8 +205,7 @@ __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict_
     for (int c = 0; c < C; ++c) {
       const float pc = __expf(Elem<T>::ld(yp + c) - mx) * inv;
       const unsigned int fg = label == c ? 1u : 0u;
-      keys[(long)c * npix + p] = kKeyOne - __float_as_uint(fminf(fabsf((float)fg - pc), 1.f));
-      vals[(long)c * npix + p] = (unsigned int)p | (fg << 31);
+      kv[(long)c * npix + p] = make_uint2(kKeyOne - __float_as_uint(fminf(fabsf((float)fg - pc), 1.f)), (unsigned int)p | (fg << 31));
     }
     if (C <= 64) atomicAdd(hist + label, 1u); else atomicAdd(counts + label, 1u);
   }
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict_
 // per class (blockIdx.y) and chunk of kChunk sorted positions (blockIdx.x): cum_i = foreground elements among positions
 // 0..i (the chunks before this one from bfg, inside the chunk a scan: 16 consecutive positions per thread), g_i = jaccard(i) -
 // jaccard(i-1); loss_c += err_i * g_i; gerr[c][orig] = g_i
-__global__ __launch_bounds__(256) void lovasz_grad_kernel(const unsigned int* __restrict__ keys_sorted, const unsigned int* __restrict__ vals_sorted,
+__global__ __launch_bounds__(256) void lovasz_grad_kernel(const uint2* __restrict__ kv_sorted,
                                                           const unsigned int* __restrict__ bfg, const unsigned int* __restrict__ counts,
                                                           float* __restrict__ gerr, double* __restrict__ lossc, long npix, int C, int nchunk) {
   __shared__ unsigned int shu[4];
@@ -214,8 +226,7 @@ __global__ __launch_bounds__(256) void lovasz_grad_kernel(const unsigned int* __
   const long nvalid = npix - (long)counts[C];
   const double gts = (double)counts[c];
   if (!(gts > 0.) || (long)blockIdx.x * kChunk >= nvalid) return;          // class absent / only void entries here (uniform)
-  const unsigned int* ks = keys_sorted + (long)c * npix;
-  const unsigned int* vs = vals_sorted + (long)c * npix;
+  const uint2* kvs = kv_sorted + (long)c * npix;
   // foreground elements in the chunks before this one
   unsigned int before = 0u;
   for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) before += bfg[(long)c * nchunk + j];
@@ -232,8 +243,8 @@ __global__ __launch_bounds__(256) void lovasz_grad_kernel(const unsigned int* __
 #pragma unroll
   for (int j = 0; j < PT; ++j) {
     const long i = i0 + j;
-    v[j] = i < nvalid ? vs[i] : 0u;
-    k[j] = i < nvalid ? ks[i] : kKeyOne;
+    const uint2 e = i < nvalid ? kvs[i] : make_uint2(kKeyOne, 0u);
+    v[j] = e.y; k[j] = e.x;
     mine += v[j] >> 31;
   }
   const unsigned int inc = wave_incl_scan(mine, lane);
@@ -263,13 +274,16 @@ __global__ __launch_bounds__(256) void lovasz_grad_kernel(const unsigned int* __
 }
 
 // gy[p,k] += w/n_present * p_k * (g_k - sum_c g_c p_c), g_c = -sign(fg_c - p_c) * gerr[c][p]  (present classes only)
-template <typename T>
+// CM > 0: C <= CM, the pixel's probabilities and gradient factors stay in registers (one exp per class instead of three)
+template <typename T, int CM>
 __global__ __launch_bounds__(256) void lovasz_backward_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ t, int ldt,
                                                               const float* __restrict__ gerr, const unsigned int* __restrict__ counts,
                                                               const double* __restrict__ lossc, T* __restrict__ gy, int ldg,
                                                               double* __restrict__ loss, long npix, int C, float weight, int ignore_void) {
   int npres = 0;
-  for (int c = 0; c < C; ++c) npres += counts[c] > 0u ? 1 : 0;
+  unsigned long long present = 0ull;                  // (CM <= 64)
+  for (int c = 0; c < C; ++c)
+    if (counts[c] > 0u) { ++npres; if (c < 64) present |= 1ull << c; }
   const float w = weight / (float)(npres > 0 ? npres : 1);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     double tot = 0.;
@@ -279,40 +293,84 @@ __global__ __launch_bounds__(256) void lovasz_backward_kernel(const T* __restric
   if (!gy) return;
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
     const T* yp = y + p * ldy;
-    float mx = -INFINITY, tbest = -INFINITY;
-    int label = 0;
-    for (int c = 0; c < C; ++c) {
-      mx = fmaxf(mx, Elem<T>::ld(yp + c));
-      const float tv = t[p * ldt + c];
-      if (tv > tbest) { tbest = tv; label = c; }
-    }
-    if (ignore_void && !(tbest > 0.f)) continue;   // void pixel: not part of the loss
-    float se = 0.f;
-    for (int c = 0; c < C; ++c) se += __expf(Elem<T>::ld(yp + c) - mx);
-    const float inv = 1.f / se;
-    float dot = 0.f;
-    for (int c = 0; c < C; ++c) {
-      if (counts[c] == 0u) continue;
-      const float pc = __expf(Elem<T>::ld(yp + c) - mx) * inv;
-      const float diff = (label == c ? 1.f : 0.f) - pc;
-      const float g = (diff > 0.f ? -1.f : (diff < 0.f ? 1.f : 0.f)) * gerr[(long)c * npix + p];
-      dot = fmaf(g, pc, dot);
-    }
-    for (int k = 0; k < C; ++k) {
-      const float pk = __expf(Elem<T>::ld(yp + k) - mx) * inv;
-      float g = 0.f;
-      if (counts[k] > 0u) {
-        const float diff = (label == k ? 1.f : 0.f) - pk;
-        g = (diff > 0.f ? -1.f : (diff < 0.f ? 1.f : 0.f)) * gerr[(long)k * npix + p];
+    if constexpr (CM > 0) {
+      float pc[CM], g[CM];
+      float mx = -INFINITY, tbest = -INFINITY;
+      int label = 0;
+#pragma unroll
+      for (int c = 0; c < CM; ++c) {
+        pc[c] = c < C ? Elem<T>::ld(yp + c) : -INFINITY;
+        mx = fmaxf(mx, pc[c]);
+        const float tv = c < C ? t[p * ldt + c] : -INFINITY;
+        if (tv > tbest) { tbest = tv; label = c; }
       }
-      T* dst = gy + p * ldg + k;
-      Elem<T>::st(dst, Elem<T>::ld(dst) + w * pk * (g - dot));
+      if (ignore_void && !(tbest > 0.f)) continue;   // void pixel: not part of the loss
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < CM; ++c) { pc[c] = c < C ? __expf(pc[c] - mx) : 0.f; se += pc[c]; }
+      const float inv = 1.f / se;
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < CM; ++c) {
+        pc[c] *= inv;
+        g[c] = 0.f;
+        if (c < C && ((present >> c) & 1ull)) {
+          const float diff = (label == c ? 1.f : 0.f) - pc[c];
+          g[c] = (diff > 0.f ? -1.f : (diff < 0.f ? 1.f : 0.f)) * gerr[(long)c * npix + p];
+          dot = fmaf(g[c], pc[c], dot);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < CM; ++k) {
+        if (k < C) {
+          T* dst = gy + p * ldg + k;
+          Elem<T>::st(dst, Elem<T>::ld(dst) + w * pc[k] * (g[k] - dot));
+        }
+      }
+    } else {
+      float mx = -INFINITY, tbest = -INFINITY;
+      int label = 0;
+      for (int c = 0; c < C; ++c) {
+        mx = fmaxf(mx, Elem<T>::ld(yp + c));
+        const float tv = t[p * ldt + c];
+        if (tv > tbest) { tbest = tv; label = c; }
+      }
+      if (ignore_void && !(tbest > 0.f)) continue;   // void pixel: not part of the loss
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += __expf(Elem<T>::ld(yp + c) - mx);
+      const float inv = 1.f / se;
+      float dot = 0.f;
+      for (int c = 0; c < C; ++c) {
+        if (counts[c] == 0u) continue;
+        const float pc = __expf(Elem<T>::ld(yp + c) - mx) * inv;
+        const float diff = (label == c ? 1.f : 0.f) - pc;
+        const float g = (diff > 0.f ? -1.f : (diff < 0.f ? 1.f : 0.f)) * gerr[(long)c * npix + p];
+        dot = fmaf(g, pc, dot);
+      }
+      for (int k = 0; k < C; ++k) {
+        const float pk = __expf(Elem<T>::ld(yp + k) - mx) * inv;
+        float g = 0.f;
+        if (counts[k] > 0u) {
+          const float diff = (label == k ? 1.f : 0.f) - pk;
+          g = (diff > 0.f ? -1.f : (diff < 0.f ? 1.f : 0.f)) * gerr[(long)k * npix + p];
+        }
+        T* dst = gy + p * ldg + k;
+        Elem<T>::st(dst, Elem<T>::ld(dst) + w * pk * (g - dot));
+      }
     }
   }
 }
 
+template <typename T>
+void launch_lovasz_backward(dim3 grid, hipStream_t s, const T* y, int ldy, const float* t, int ldt, const float* gerr, const unsigned int* counts,
+                            const double* lossc, T* gy, int ldg, double* loss, long npix, int C, float weight, int ignore_void) {
+  if (C <= 4) hipLaunchKernelGGL((lovasz_backward_kernel<T, 4>), grid, dim3(256), 0, s, y, ldy, t, ldt, gerr, counts, lossc, gy, ldg, loss, npix, C, weight, ignore_void);
+  else if (C <= 32) hipLaunchKernelGGL((lovasz_backward_kernel<T, 32>), grid, dim3(256), 0, s, y, ldy, t, ldt, gerr, counts, lossc, gy, ldg, loss, npix, C, weight, ignore_void);
+  else hipLaunchKernelGGL((lovasz_backward_kernel<T, 0>), grid, dim3(256), 0, s, y, ldy, t, ldt, gerr, counts, lossc, gy, ldg, loss, npix, C, weight, ignore_void);
+}
+
 struct Layout {
-  size_t keys_a, keys_b, vals_a, vals_b, gerr, counts, lossc, bfg, table, total;
+  size_t kv_a, kv_b, gerr, counts, lossc, bfg, tot, table, total;
   int cols, nchunk;
 };
 
@@ -323,14 +381,13 @@ Layout layout(long npix, int C) {
   L.cols = (int)((npix + kSortKPW - 1) / kSortKPW);
   L.nchunk = (int)((npix + kChunk - 1) / kChunk);
   size_t off = 0;
-  L.keys_a = off; off = al(off + n * 4);
-  L.keys_b = off; off = al(off + n * 4);
-  L.vals_a = off; off = al(off + n * 4);
-  L.vals_b = off; off = al(off + n * 4);
+  L.kv_a = off; off = al(off + n * 8);
+  L.kv_b = off; off = al(off + n * 8);
   L.gerr = off; off = al(off + n * 4);
   L.counts = off; off = al(off + (size_t)(C + 1) * 4);
   L.lossc = off; off = al(off + (size_t)C * 8);
   L.bfg = off; off = al(off + (size_t)C * L.nchunk * 4);
+  L.tot = off; off = al(off + (size_t)C * 256 * 4);
   L.table = off; off = al(off + (size_t)C * 256 * L.cols * 4);
   L.total = off;
   return L;
@@ -370,37 +427,37 @@ extern "C" int sdhip_lovasz_softmax(const void* logits, int ldy, const float* ta
   SDHIP_CHECK_ARG((size_t)workspace_bytes >= L.total, "lovasz_softmax: workspace too small (%ld < %zu)", workspace_bytes, L.total);
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
-  unsigned int* keys_a = (unsigned int*)(ws + L.keys_a); unsigned int* keys_b = (unsigned int*)(ws + L.keys_b);
-  unsigned int* vals_a = (unsigned int*)(ws + L.vals_a); unsigned int* vals_b = (unsigned int*)(ws + L.vals_b);
+  uint2* kv_a = (uint2*)(ws + L.kv_a); uint2* kv_b = (uint2*)(ws + L.kv_b);       // (key, index | fg << 31) pairs: one 8-byte store per element and pass
   float* gerr = (float*)(ws + L.gerr);
   unsigned int* counts = (unsigned int*)(ws + L.counts);
   double* lossc = (double*)(ws + L.lossc);
   unsigned int* bfg = (unsigned int*)(ws + L.bfg);
   unsigned int* table = (unsigned int*)(ws + L.table);
+  unsigned int* tot = (unsigned int*)(ws + L.tot);
   SDHIP_CHECK_ARG(C <= 65535, "lovasz_softmax: more than 65535 classes");
   // (a kernel, not hipMemsetAsync: the step is replayed from a hipGraph, and everything in it is kept to kernel nodes)
   if (sdhip_zero_async(ws + L.counts, L.bfg - L.counts, s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "lovasz_softmax: clearing the counters failed");
   if (dtype == SDHIP_F32)
-    hipLaunchKernelGGL(lovasz_errors_kernel<float>, grid_for(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, keys_a, vals_a, counts, npix, C, ignore_void);
+    hipLaunchKernelGGL(lovasz_errors_kernel<float>, grid_for(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, kv_a, counts, npix, C, ignore_void);
   else
-    hipLaunchKernelGGL(lovasz_errors_kernel<bf16_t>, grid_for(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, keys_a, vals_a, counts, npix, C, ignore_void);
+    hipLaunchKernelGGL(lovasz_errors_kernel<bf16_t>, grid_for(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, kv_a, counts, npix, C, ignore_void);
   // four stable passes over bits 0-7, 8-15, 16-23, 24-31 (keys < 2^30); a -> b -> a -> b -> a: the sorted arrays end in `a`
   const dim3 gs((unsigned)((L.cols + 3) / 4), (unsigned)C);
   for (int pass = 0; pass < 4; ++pass) {
-    const unsigned int* kin = (pass & 1) ? keys_b : keys_a; const unsigned int* vin = (pass & 1) ? vals_b : vals_a;
-    unsigned int* kout = (pass & 1) ? keys_a : keys_b; unsigned int* vout = (pass & 1) ? vals_a : vals_b;
+    const uint2* kin = (pass & 1) ? kv_b : kv_a;
+    uint2* kout = (pass & 1) ? kv_a : kv_b;
     hipLaunchKernelGGL(sort_hist_kernel, gs, dim3(256), 0, s, kin, table, npix, L.cols, 8 * pass);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)C), dim3(1024), 0, s, table, L.cols);
-    hipLaunchKernelGGL(sort_scatter_kernel, gs, dim3(256), 0, s, kin, vin, kout, vout, (const unsigned int*)table, npix, L.cols, 8 * pass);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)(C * 64)), dim3(256), 0, s, table, tot, L.cols, C * 256);
+    hipLaunchKernelGGL(sort_scatter_kernel, gs, dim3(256), 0, s, kin, kout, (const unsigned int*)table, (const unsigned int*)tot, npix, L.cols, 8 * pass);
   }
   const dim3 gc((unsigned)L.nchunk, (unsigned)C);
-  hipLaunchKernelGGL(lovasz_fgcount_kernel, gc, dim3(256), 0, s, (const unsigned int*)vals_a, bfg, npix, L.nchunk);
-  hipLaunchKernelGGL(lovasz_grad_kernel, gc, dim3(256), 0, s, (const unsigned int*)keys_a, (const unsigned int*)vals_a, (const unsigned int*)bfg,
+  hipLaunchKernelGGL(lovasz_fgcount_kernel, gc, dim3(256), 0, s, (const uint2*)kv_a, bfg, npix, L.nchunk);
+  hipLaunchKernelGGL(lovasz_grad_kernel, gc, dim3(256), 0, s, (const uint2*)kv_a, (const unsigned int*)bfg,
                      (const unsigned int*)counts, gerr, lossc, npix, C, L.nchunk);
   if (dtype == SDHIP_F32)
-    hipLaunchKernelGGL(lovasz_backward_kernel<float>, grid_stream(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, gerr, counts, lossc, (float*)grad, ldg, loss, npix, C, weight, ignore_void);
+    launch_lovasz_backward<float>(grid_stream(npix), s, (const float*)logits, ldy, target, ldt, gerr, counts, lossc, (float*)grad, ldg, loss, npix, C, weight, ignore_void);
   else
-    hipLaunchKernelGGL(lovasz_backward_kernel<bf16_t>, grid_stream(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, gerr, counts, lossc, (bf16_t*)grad, ldg, loss, npix, C, weight, ignore_void);
+    launch_lovasz_backward<bf16_t>(grid_stream(npix), s, (const bf16_t*)logits, ldy, target, ldt, gerr, counts, lossc, (bf16_t*)grad, ldg, loss, npix, C, weight, ignore_void);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }

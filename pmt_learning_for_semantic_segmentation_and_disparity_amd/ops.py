@@ -1494,9 +1494,10 @@ def conv3d_spec(x, D, weight, stride=1, padding=1):
     return ConvSpec('conv', kh, kw, stride, 1, padding, padding, Ho, Wo, D, Do, kd, stride, padding)
 
 
-def conv3d_bn_act(x, D, weight, bn, stride=1, padding=1, act=0, residual=None, groups=1):
+def conv3d_bn_act(x, D, weight, bn, stride=1, padding=1, act=0, residual=None, groups=1, in_slot=None, res_slot=None):
+    """in_slot / res_slot: see conv_bn_act (GradSlot)."""
     spec = conv3d_spec(x, D, weight, stride, padding)
-    return _ConvBNActFn.apply(x, weight, bn.weight, bn.bias, residual, spec, bn, act, groups), spec.Do
+    return _ConvBNActFn.apply(x, weight, bn.weight, bn.bias, residual, spec, bn, act, groups, in_slot, res_slot), spec.Do
 
 
 def conv3d(x, D, weight, stride=1, padding=1):

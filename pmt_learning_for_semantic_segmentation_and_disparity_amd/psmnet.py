@@ -32,10 +32,10 @@ def _run2d(seq, x, act=0, residual=None, groups=1, in_slot=None, res_slot=None):
                            act=act, residual=residual, groups=groups, in_slot=in_slot, res_slot=res_slot)
 
 
-def _run3d(seq, x, D, act=0, residual=None, groups=1):
+def _run3d(seq, x, D, act=0, residual=None, groups=1, in_slot=None, res_slot=None):
     c = seq[0]
     return ops.conv3d_bn_act(x, D, c.weight, seq[1], stride=c.stride[0], padding=c.padding[0], act=act, residual=residual,
-                             groups=groups)
+                             groups=groups, in_slot=in_slot, res_slot=res_slot)
 
 
 class BasicBlock(nn.Module):
@@ -197,8 +197,11 @@ class PSMNet(nn.Module):
         cost = ops.cost_volume(ref, tgt, D)                   # (B*D, 64, H/4, W/4)
         c0, _ = _run3d(self.dres0[0], cost, D, act=1)
         c0, _ = _run3d(self.dres0[2], c0, D, act=1)
-        c1, _ = _run3d(self.dres1[0], c0, D, act=1)
-        cost0, _ = _run3d(self.dres1[2], c1, D, act=0, residual=c0)
+        # c0 feeds dres1[0] and the skip add behind dres1[2] (stackhourglass.py:122-123): the skip gradient is parked and dres1[0]'s
+        # data gradient accumulates onto it (ops.GradSlot) instead of autograd adding two 32-channel volumes
+        slot = ops.GradSlot(exclusive=True) if (torch.is_grad_enabled() and c0.requires_grad) else None
+        c1, _ = _run3d(self.dres1[0], c0, D, act=1, in_slot=slot)
+        cost0, _ = _run3d(self.dres1[2], c1, D, act=0, residual=c0, res_slot=slot)
         out1, pre1, post1 = self.dres2(cost0, D, None, None, add_out=cost0)
         out2, pre2, post2 = self.dres3(out1, D, pre1, post1, add_out=cost0)
         out3, pre3, post3 = self.dres4(out2, D, pre1, post2, add_out=cost0)   # pre1, as in the reference (:130)

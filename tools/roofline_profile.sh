@@ -27,4 +27,9 @@ for m in dsnet psmnet; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_$m -o r -- python bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > $OUT/step_$m.log 2>&1
   python tools/trace_summary.py $OUT/step_$m/r_kernel_trace.csv > ${SDHIP_PROFILE_DIR:-gpurun_out/profiles}/${SDHIP_PROFILE_TAG:-r03}_${m}_step_summary.txt
 done
+# the per-GPU workloads of BASELINE configs 4 (PSMNet(192) 960x512 B=4) and 5 (minidsnetExt aspp=2 hanet=1 19 classes, 1024x512 B=4)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_psm4 -o r -- python bench.py --model psmnet --batch 4 --height 512 --width 960 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > $OUT/step_psm4.log 2>&1
+python tools/trace_summary.py $OUT/step_psm4/r_kernel_trace.csv > ${SDHIP_PROFILE_DIR:-gpurun_out/profiles}/${SDHIP_PROFILE_TAG:-r03}_psmnet_cfg4_step_summary.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_cfg5 -o r -- python bench.py --model minidsnetExt_cfg5 --batch 4 --height 512 --width 1024 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > $OUT/step_cfg5.log 2>&1
+python tools/trace_summary.py $OUT/step_cfg5/r_kernel_trace.csv > ${SDHIP_PROFILE_DIR:-gpurun_out/profiles}/${SDHIP_PROFILE_TAG:-r03}_cfg5_step_summary.txt
 tail -1 $OUT/stats.log

@@ -38,6 +38,8 @@ struct BandArgs {
   long rep_stride;
   int tiles_w, tiles_hw, ntiles, tpw;      // tiles per output row / per image / in total / per workgroup
   unsigned magic_hw, magic_tw;             // div_magic(tiles_hw), div_magic(tiles_w)
+  int D, Do, pad_d;                        // volumes (KD = 3): input / output depth, front padding; B counts batch entries then
+  unsigned magic_do;                       // div_magic(Do)
   int dbg;                                 // diagnostic bits (SDHIP_TUNE_BAND_DBG): 1 no halo prefetch, 2 no weight DMA, 4 no MFMA, 8 no stores
 };
 
@@ -46,7 +48,7 @@ template <int I, int N, typename F> __device__ __forceinline__ void band_static_
 }
 template <int N> __device__ __forceinline__ void band_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-template <int K, int BN, int NW = 8>
+template <int K, int BN, int NW = 8, int KD = 1>
 struct BandCfg {
   static constexpr int RPR = NW * 16;                    // LDS rows (64 bytes) one DMA round of the workgroup fills
   static constexpr int RPW = 16 / NW;                    // output pixel rows per wave
@@ -60,7 +62,7 @@ struct BandCfg {
   // chunk of every tile uses the same ones — so the stage loop issues halo DMA only.
   static constexpr int RS = K == 3 ? 3 : 1;
   static constexpr int NSTG = K / RS;                    // stages per chunk
-  static constexpr bool WRES = NSTG == 1;                // weights resident (host: single channel half)
+  static constexpr bool WRES = NSTG == 1 && KD == 1;     // weights resident (host: single channel half); KD = 3: every depth tap is a chunk with weights of its own, streamed like the 5x5 stages
   static constexpr int TPS = RS * K;                     // taps per stage
   static constexpr int WROWS = TPS * BN;
   static constexpr int WR = (WROWS + RPR - 1) / RPR;
@@ -98,11 +100,11 @@ __device__ __forceinline__ band_rsrc_t band_rsrc(const void* base) {
   return r;
 }
 
-template <int K, int BN, int VAR, int NW>
+template <int K, int BN, int VAR, int NW, int KD = 1>
 __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
   constexpr bool DBG = (VAR & 128) != 0;                  // diagnostic build: honours p.dbg (timing breakdowns, wrong results)
   const int dbg = DBG ? p.dbg : 0;
-  using C = BandCfg<K, BN, NW>;
+  using C = BandCfg<K, BN, NW, KD>;
   using T = bf16_t;
   constexpr int IWp = C::IWp, IW = C::IW, HB = C::HB, WB = C::WB, RPR = C::RPR, RPW = C::RPW;
   constexpr int NT_CO = BN / 16, NT_PIX = 2 * RPW;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
   const int t_begin = blockIdx.x * p.tpw;
   const int t_end = min(p.ntiles, t_begin + p.tpw);
   if (t_begin >= t_end) return;                          // (host launches no such workgroup)
-  const int nhalf = p.Cin > 32 ? 2 : 1;
+  const int nhalf = KD > 1 ? KD : (p.Cin > 32 ? 2 : 1);   // chunks per tile: channel halves, or (volumes, <= 32 channels) depth taps
   const int nchunks = (t_end - t_begin) * nhalf;
 
   // ---- LDS-DMA source side ----
@@ -128,7 +130,11 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
   const band_rsrc_t xr = band_rsrc(p.x), wr = band_rsrc(p.wp);
   const int img_bytes = p.H * p.W * p.ldx * 2;
 
+  // volumes: z runs fastest, so that a workgroup walks its spatial tile through consecutive output slices and finds two of the
+  // three input slices of a tile in its XCD's L2 (it loaded them for the tile before); b counts batch entries, zt is the slice
+  int czt = 0;                                            // output slice of the tile decoded last
   auto tile_of = [&](int t, int& b, int& oh0, int& ow0) {
+    if constexpr (KD > 1) { const int q = fast_div(t, p.Do, p.magic_do); czt = t - q * p.Do; t = q; }
     b = fast_div(t, p.tiles_hw, p.magic_hw);
     const int r = t - b * p.tiles_hw;
     const int ty = fast_div(r, p.tiles_w, p.magic_tw);
@@ -148,8 +154,17 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
       hv[r] = in ? ((gh * p.W + gw) * p.ldx + c_l * 8) * 2 : kBandOob;
     }
   };
-  auto halo_dma = [&](int r, int soff, int hsel) {         // round r of the image at byte offset soff into halo buffer hsel
-    if (r < C::HR && r * RPR + wave * 16 < C::HROWS) band_dma(hv[r], xr, hsel * HB + r * (RPR * 64) + wave_lds, soff);   // wave-uniform
+  auto halo_dma = [&](int r, int soff, int hsel) {         // round r of the image at byte offset soff (< 0: a slice outside the volume, zeros) into halo buffer hsel
+    if (r < C::HR && r * RPR + wave * 16 < C::HROWS) band_dma(soff >= 0 ? hv[r] : kBandOob, xr, hsel * HB + r * (RPR * 64) + wave_lds, soff >= 0 ? soff : 0);   // wave-uniform
+  };
+  // byte offset of the image a chunk reads: (batch entry / image b, chunk h of output slice zt)
+  auto chunk_src = [&](int b, int zt, int h) -> int {
+    if constexpr (KD > 1) {
+      const int zin = zt + h - p.pad_d;
+      return (zin >= 0 && zin < p.D) ? (b * p.D + zin) * img_bytes : -1;
+    } else {
+      return b * img_bytes + h * 64;
+    }
   };
   // weights: row tap*BN + m of a stage <- row (j*K + tap)*Mpad + m of the packed [T][Mpad][64] image
   int wv[C::WR];
@@ -160,8 +175,9 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
     wv[r] = (tap * p.Mpad + m) * 128 + c_l * 16;
   }
   const int wrow_bytes = C::TPS * p.Mpad * 128;            // one stage (RS kernel rows) of the packed image
-  auto w_dma = [&](int r, int j, int h, int wsel) {
-    if (r < C::WR && r * RPR + wave * 16 < C::WROWS) band_dma(wv[r], wr, 2 * HB + wsel * WB + r * (RPR * 64) + wave_lds, j * wrow_bytes + h * 64);
+  auto w_dma = [&](int r, int j, int h, int wsel) {         // stage j of chunk h: channel half h (+64 bytes in the packed row) or depth tap h (its own 3x3 image)
+    if (r < C::WR && r * RPR + wave * 16 < C::WROWS)
+      band_dma(wv[r], wr, 2 * HB + wsel * WB + r * (RPR * 64) + wave_lds, j * wrow_bytes + (KD > 1 ? h * wrow_bytes : h * 64));
   };
 
   // ---- fragment addressing ----
@@ -223,7 +239,8 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
 #pragma unroll
   for (int r = 0; r < C::WR; ++r) w_dma(r, 0, 0, 0);
 #pragma unroll
-  for (int r = 0; r < C::HR; ++r) halo_dma(r, cb * img_bytes, 0);
+  for (int r = 0; r < C::HR; ++r) halo_dma(r, chunk_src(cb, czt, 0), 0);
+  int cz = czt;                                            // output slice of the current tile
   int wsel = 0;
   bool epi_counted = false;                                // the previous chunk ended with exactly NSTORE stores per lane
 
@@ -231,12 +248,12 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
     const int hsel = c & 1;
     const bool has_next = c + 1 < nchunks;
     // next chunk
-    int nb = cb, noh0 = coh0, now0 = cow0, nh = ch_half + 1, nt = ct;
+    int nb = cb, noh0 = coh0, now0 = cow0, nh = ch_half + 1, nt = ct, nz = cz;
     if (nh == nhalf) {
       nh = 0; nt = ct + 1;
-      if (has_next) { tile_of(nt, nb, noh0, now0); halo_offsets(noh0, now0); }
+      if (has_next) { tile_of(nt, nb, noh0, now0); halo_offsets(noh0, now0); nz = czt; }
     }
-    const int nsoff = nb * img_bytes + nh * 64;
+    const int nsoff = chunk_src(nb, nz, nh);
     if (ch_half == 0) {
 #pragma unroll
       for (int mi = 0; mi < NT_CO; ++mi)
@@ -318,7 +335,8 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
     epi_counted = false;
     if (ch_half == nhalf - 1) {
       // ---- epilogue of tile ct: bias / activation / store / BatchNorm statistics of the stored values ----
-      const int grp = cb < p.bpg ? 0 : cb / p.bpg;
+      const int oimg = KD > 1 ? cb * p.Do + cz : cb;        // output image (slice)
+      const int grp = oimg < p.bpg ? 0 : oimg / p.bpg;
       if (p.bias) {
 #pragma unroll
         for (int mi = 0; mi < NT_CO; ++mi)
@@ -342,8 +360,8 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 1.f / (1.f + __expf(-acc[mi][ni][r]));
       }
-      T* const yb = (T*)p.y + (long)cb * p.Ho * p.Wo * p.ldy;
-      const T* const rb = (const T*)p.res + (long)cb * p.Ho * p.Wo * p.ldres;
+      T* const yb = (T*)p.y + (long)oimg * p.Ho * p.Wo * p.ldy;
+      const T* const rb = (const T*)p.res + (long)oimg * p.Ho * p.Wo * p.ldres;
       const bool interior = coh0 + C::TH <= p.Ho && cow0 + C::TW <= p.Wo && BN <= p.Cout;   // workgroup-uniform
       if (interior) {
         // 16-byte stores: v_permlane16_swap trades the 4 channels a lane holds for pixel tile 2q+1 against the NEXT 4
@@ -442,37 +460,39 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
         }
       }
       if (p.stats) {
-        const int ngrp = nb < p.bpg ? 0 : nb / p.bpg;
+        const int nimg = KD > 1 ? nb * p.Do + nz : nb;
+        const int ngrp = nimg < p.bpg ? 0 : nimg / p.bpg;
         if (!has_next || ngrp != grp) { flush_stats(grp); epi_counted = false; }   // workgroup-uniform
       }
     }
-    cb = nb; coh0 = noh0; cow0 = now0; ch_half = nh; ct = nt;
+    cb = nb; coh0 = noh0; cow0 = now0; ch_half = nh; ct = nt; cz = nz;
   }
 }
 
 inline bool band_ok(int ntiles) { return ntiles >= 192 && ntiles < 65536; }
 
-template <int K, int BN, int VAR, int NW = 8>
+template <int K, int BN, int VAR, int NW = 8, int KD = 1>
 int launch_band_bn(const BandArgs& a, int grid, hipStream_t s) {
-  auto kern = conv_band_kernel<K, BN, VAR, NW>;
+  auto kern = conv_band_kernel<K, BN, VAR, NW, KD>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       SDHIP_FAIL(SDHIP_ERR_LAUNCH, "conv_band: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  const size_t lds = BandCfg<K, BN, NW>::LDS;
+  const size_t lds = BandCfg<K, BN, NW, KD>::LDS;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, a);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }
 
-template <int K>
+template <int K, int KD = 1>
 int launch_band(BandArgs& a, hipStream_t s) {
   const int tiles_h = sdhip_cdiv(a.Ho, 16);
   a.tiles_w = sdhip_cdiv(a.Wo, 32);
   a.tiles_hw = tiles_h * a.tiles_w;
-  a.ntiles = a.tiles_hw * a.B;
+  a.ntiles = a.tiles_hw * a.B * (KD > 1 ? a.Do : 1);
+  a.magic_do = (KD > 1 && a.Do > 1) ? (unsigned)(0x100000000ULL / (unsigned)a.Do) + 1u : 0u;
   a.magic_hw = a.tiles_hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.tiles_hw) + 1u : 0u;
   a.magic_tw = a.tiles_w > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.tiles_w) + 1u : 0u;
   a.tpw = sdhip_cdiv(a.ntiles, 256);
@@ -484,6 +504,8 @@ int launch_band(BandArgs& a, hipStream_t s) {
   a.dbg &= 0xff;
   if constexpr (K == 5) {
     if (a.Mpad > 32) return a.dbg ? launch_band_bn<K, 64, 128 + 5>(a, grid, s) : launch_band_bn<K, 64, 5>(a, grid, s);
+  } else if constexpr (KD > 1) {
+    return launch_band_bn<K, 32, 5, 8, KD>(a, grid, s);      // (host: <= 32 channels on both sides)
   } else {
     if (a.Mpad > 32) return launch_band_bn<K, 64, 5>(a, grid, s);
   }

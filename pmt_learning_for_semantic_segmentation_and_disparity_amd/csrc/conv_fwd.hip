@@ -548,7 +548,23 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
     f.Cin = Cin; f.ldx = ldx; f.Cout = Cout; f.Mpad = a.Mpad; f.ldy = ldy;
     f.bpg = B / groups; f.act = act; f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride;
     f.res = addend ? addend : (accumulate ? y : nullptr); f.ldres = addend ? ldadd : ldy;
+    f.D = 1; f.Do = 1; f.pad_d = 0;
     return band5 ? launch_band<5>(f, s) : launch_band<3>(f, s);
+  }
+  // ---- the same kernel over volumes: 3x3x3, <= 32 channels on both sides (PSMNet's 32 -> 32 stack, stackhourglass.py:59-102):
+  //      every depth tap is a chunk of its tile (its own input slice and 3x3 weights), z runs fastest over a workgroup's tiles ----
+  if (!ps && !bx && omul == 1 && dtype == SDHIP_BF16 && kh == 3 && kw == 3 && kd == 3 && sd == 1 && stride == 1 && dil == 1 && Cin <= 32 && Cin % 8 == 0 &&
+      a.Mpad == 32 && !in_scale && !((accumulate || addend) && stats) && !(accumulate && addend) &&
+      (!addend || (ldadd % 8 == 0 && ((uintptr_t)addend & 15) == 0)) && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
+      (long)B * D * H * W * ldx * 2 < (long)kBandOob && band_ok(sdhip_cdiv(Ho, 16) * sdhip_cdiv(Wo, 32) * B * Do) && !dg.conv_generic && !dg.conv_no_band && !dg.conv_no_band3) {
+    BandArgs f;
+    f.x = x; f.wp = wpacked; f.y = y; f.bias = bias; f.stats = stats;
+    f.B = B; f.H = H; f.W = W; f.Ho = Ho; f.Wo = Wo; f.pad_t = pad_t; f.pad_l = pad_l;
+    f.D = D; f.Do = Do; f.pad_d = pad_d;
+    f.Cin = Cin; f.ldx = ldx; f.Cout = Cout; f.Mpad = a.Mpad; f.ldy = ldy;
+    f.bpg = (B / groups) * Do; f.act = act; f.stats_ld = a.stats_ld; f.nrep = a.nrep; f.rep_stride = a.rep_stride;
+    f.res = addend ? addend : (accumulate ? y : nullptr); f.ldres = addend ? ldadd : ldy;
+    return launch_band<3, 3>(f, s);
   }
   if (addend && !bx) SDHIP_FAIL(SDHIP_ERR_UNSUPPORTED, "conv2d_fwd_add: only the persistent 5x5 kernel adds a second tensor in its epilogue (bf16, <= 64 channels, >= 192 tiles of 16x32)");
   // ---- fast path (conv_fast.h): 16-byte-aligned pixels on both sides, halo-tile mode ----

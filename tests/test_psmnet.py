@@ -97,6 +97,56 @@ def test_hip_conv3d_bf16_single_map_head(B, co, D, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,ci,co,D,H,W", [(2, 32, 32, 7, 70, 100), (1, 24, 32, 48, 64, 128), (4, 32, 24, 5, 33, 130)])
+def test_hip_conv3d_bf16_persistent_volume_kernel(B, ci, co, D, H, W):
+    """3x3x3, <= 32 channels on both sides, bf16 on the persistent kernel (conv_band.h with depth taps as chunks: PSMNet's
+    32 -> 32 stack): forward and data gradient against f32 ATen on the same bf16-rounded operands; convbn_3d + ReLU + skip in
+    training mode (statistics from the epilogue, the data gradient accumulated onto a parked skip gradient) against the
+    halo-tile kernel (SDHIP_CONV_NO_BAND3): outputs, gradients and running statistics."""
+    import os
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops, _lib
+    g = torch.Generator().manual_seed(B * 100 + D)
+    x = torch.randn(B, ci, D, H, W, generator=g).bfloat16()
+    w = (torch.randn(co, ci, 3, 3, 3, generator=g) * 0.05)
+    gy = torch.randn(B, co, D, H, W, generator=g).bfloat16()
+    xr = x.float().requires_grad_(True)
+    yr = F.conv3d(xr, w.bfloat16().float(), None, padding=1)
+    yr.backward(gy.float())
+    wd = w.cuda().requires_grad_(True)
+    xd = _vol_to_images(x.cuda()).requires_grad_(True)
+    yd, Do = ops.conv3d(xd, D, wd, 1, 1)
+    yd.backward(_vol_to_images(gy.cuda()))
+    torch.cuda.synchronize()
+    tol = 2.0 ** -7
+    assert _rel(_images_to_vol(yd, B).float().cpu(), yr.detach()) < tol
+    assert _rel(_images_to_vol(xd.grad, B).float().cpu(), xr.grad) < tol
+    if ci != co:
+        return
+    # convbn_3d + ReLU, then convbn_3d + skip (the shape of dres1, stackhourglass.py:65-68), both kernels
+    res = {}
+    for sw in ("", "1"):
+        if sw:
+            os.environ["SDHIP_CONV_NO_BAND3"] = sw
+        else:
+            os.environ.pop("SDHIP_CONV_NO_BAND3", None)
+        _lib.reload_diag()
+        torch.manual_seed(5)
+        bn1, bn2 = nn.BatchNorm3d(co).cuda().train(), nn.BatchNorm3d(co).cuda().train()
+        w1 = w.cuda().requires_grad_(True); w2 = (w * 0.5).cuda().requires_grad_(True)
+        x0 = _vol_to_images(x.cuda()).requires_grad_(True)
+        slot = ops.GradSlot(exclusive=True)
+        h, _ = ops.conv3d_bn_act(x0, D, w1, bn1, act=1, in_slot=slot)
+        y, _ = ops.conv3d_bn_act(h, D, w2, bn2, act=0, residual=x0, res_slot=slot)
+        y.backward(_vol_to_images(gy.cuda()))
+        torch.cuda.synchronize()
+        res[sw] = (y.detach().float(), x0.grad.float(), bn1.running_var.clone(), bn2.running_mean.clone(), bn1.weight.grad.clone())
+    os.environ.pop("SDHIP_CONV_NO_BAND3", None)
+    _lib.reload_diag()
+    for a, b in zip(res[""], res["1"]):
+        assert _rel(a, b) < 2.0 ** -6, _rel(a, b)
+
+
+@pytest.mark.gpu
 def test_hip_deconv3d_bn_matches_torch():
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops
     torch.manual_seed(0)

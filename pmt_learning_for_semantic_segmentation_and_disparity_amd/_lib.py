@@ -167,6 +167,7 @@ DIAG_NO_FUSED_BN = bool(_diag_switch("SDHIP_DIAG_NO_FUSED_BN"))
 DIAG_NO_SIDE = bool(_diag_switch("SDHIP_DIAG_NO_SIDE"))
 DIAG_NO_GRAD_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_GRAD_SLOTS"))
 DIAG_NO_WGRAD_GROUP = bool(_diag_switch("SDHIP_DIAG_NO_WGRAD_GROUP"))
+DIAG_NO_PHASE_DGRAD = bool(_diag_switch("SDHIP_DIAG_NO_PHASE_DGRAD"))     # data gradient of stride-2 3-D convolutions over the zero-stuffed dY (A/B)
 TUNE_WGRAD_OVERLAP = bool(_diag_switch("SDHIP_TUNE_WGRAD_OVERLAP"))     # measured and not kept as a default: see train.TrainStep
 TUNE_OVERLAP_WG = int(_diag_switch("SDHIP_TUNE_OVERLAP_WG") or 128)
 DIAG_NO_BN_SLOTS = bool(_diag_switch("SDHIP_DIAG_NO_BN_SLOTS"))

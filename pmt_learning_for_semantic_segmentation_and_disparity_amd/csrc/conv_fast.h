@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const FastArgs p) {
   constexpr int CH = 4 * KS;
   constexpr int TWT = TW / 16, NPT = TH * TWT, NT_PIX = NPT / 4, NT_CO = BN / 16;
   constexpr bool PF = (TH * TW <= 64);    // small tiles: halo register-prefetched and double-buffered
-  constexpr int HPF = 5;                  // load rounds of the prefetched (small-tile) halo
+  constexpr int HPF = (DMA && KS == 1) ? 6 : 5;   // load rounds of the prefetched (small-tile) halo (6: the 9 x 40 64-byte rows of a stride-2 3x3 tile; DMA kernels hold no data registers for it)
   static_assert(NPT % 4 == 0 && NT_PIX >= 1, "every wave needs at least one 16-pixel MFMA tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 

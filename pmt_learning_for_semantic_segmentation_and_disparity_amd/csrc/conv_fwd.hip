@@ -471,6 +471,10 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
   const int tune_big = dg.tune_big, tune_split = dg.tune_split;
   const int tune_ksoft_small = 80, tune_ksoft_big = 80;
   bool big = (blocks_big >= tune_big && Wo >= 24) || dg.conv_big;
+  // stride-2 volumes (hourglass conv1 / conv3 and the adjoint of conv5 / conv6, stackhourglass.py:13-29): the 8x32 tile's halo is
+  // 17 x 72 rows per depth tap — 78 KB single-buffered, one workgroup per CU, staging and arithmetic in turn (0.26 PFLOP/s);
+  // the 4x16 tile's 9 x 40 rows double-buffer and leave room for a second workgroup
+  if (stride == 2 && kd > 1 && !dg.conv_big && dg.tune_s2_small) big = false;
   if (!big) {
     // small feature maps (DenseNet blocks 2-4, pooled pyramids): the launch cannot fill 256 CUs with pixel tiles alone,
     // so split the output channels over more workgroups (the input tile is re-read from L2, the serial
@@ -598,7 +602,7 @@ static int conv2d_fwd_impl(const void* x, const void* wpacked, void* y,
       const int hrows = ((IH * IWp + px_per_round - 1) / px_per_round) * px_per_round;   // whole load rounds
       const int nqq_f = kd * (ks == 2 ? sdhip_cdiv(Cin, CKh) : 1);
       const size_t hb = (size_t)hrows * rb * ((fbig || nqq_f == 1) ? 1 : 2);   // small tiles double-buffer the halo across chunks
-      if (!fbig && hrows > 5 * px_per_round) { fbig = true; continue; }   // small-tile halo prefetch plan: 5 rounds
+      if (!fbig && hrows > ((f.dma && ks == 1) ? 6 : 5) * px_per_round) { fbig = true; continue; }   // small-tile halo prefetch plan: 5 / 6 rounds (conv_fast.h HPF)
       auto wbuf = [&](int tgv) { return (size_t)(((tgv * bn + px_per_round - 1) / px_per_round) * px_per_round) * rb; };
       int tg = T;
       const size_t ksoft_f = (size_t)(fbig ? tune_ksoft_big : tune_ksoft_small) * 1024;

@@ -45,6 +45,7 @@ static void diag_fill() {
   g_diag.corr_no_tiled = env_set("SDHIP_CORR_NO_TILED");
   g_diag.wgrad_no_half32 = env_set("SDHIP_WGRAD_NO_HALF32");
   g_diag.wgrad_split2d = env_set("SDHIP_WGRAD_SPLIT2D");
+  g_diag.tune_s2_small = env_int("SDHIP_TUNE_S2_SMALL", 1);
   g_diag.tune_big = env_int("SDHIP_TUNE_BIG", 512);
   g_diag.tune_split = env_int("SDHIP_TUNE_SPLIT", 1024);
   g_diag.tune_thin_blocks = env_int("SDHIP_TUNE_THIN_BLOCKS", 1024);

@@ -30,6 +30,7 @@ void sdhip_set_error(const char* fmt, ...);
 // ---- diagnostic / tuning switches (runtime.hip): environment read once at library load ----
 struct SdhipDiag {
   bool conv_generic, conv_big, conv_no_thin, conv_no_gemm, conv_no_band, conv_no_band3, wgrad_generic, wgrad_no_pack, wgrad_force_pack, wgrad_no_half, thin_wgrad_reg, corr_no_tiled, wgrad_no_half32, wgrad_split2d;
+  int tune_s2_small;
   int tune_big, tune_split, tune_thin_blocks, tune_fused_blocks, tune_gemm_dbg, tune_band_dbg;
   double tune_atomic_tbs;
 };

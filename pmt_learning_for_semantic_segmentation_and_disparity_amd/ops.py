@@ -343,6 +343,10 @@ def pack_descriptors(dtype, owners=None):
             if dt != dtype:
                 continue
             dtc = _lib.BF16 if dt == torch.bfloat16 else _lib.F32
+            if kind == 'phase':     # the eight sub-pixel sub-kernels of a 3x3x3 stride-2 weight: one single-tap row per tap
+                for src_off, dst_off, M, K, T, sm, sk, flip in _phase_rows(w, dtc)[0]:
+                    rows.append([w.data_ptr() + 4 * src_off, buf.data_ptr() + buf.element_size() * dst_off, M, K, T, sm, sk, flip])
+                continue
             prow = _pack_rows(w, kind, mode, dtc)
             per = _lib.packed_elems(prow[0][2], prow[0][3], prow[0][4], dtc)
             for src_off, dst_blk, M, K, T, sm, sk, flip in prow:
@@ -565,6 +569,20 @@ def _conv_backward(ctx_spec, xv, ldx, weight, g, ldg, in_scale, in_shift, in_rel
                 fused_bn = True
             elif rc != _lib.ERR_UNSUPPORTED:
                 raise _lib.SdhipError("sdhip_conv2d_fwd_bnbwd failed (%d): %s" % (rc, _lib._lib.sdhip_last_error().decode()))
+        # Conv3d(k=3, stride 2, padding 1) over even extents (hourglass conv1 / conv3, stackhourglass.py:13-19): its data gradient is
+        # the transposed convolution that doubles every extent — eight sub-pixel phases of 1..8 taps over dY itself (27 taps per dY
+        # voxel), not a stride-1 correlation over the zero-stuffed dY (8 x 27: seven of eight products are zeros)
+        if (not fused_bn and acc_into is None and addend is None and spec.kind == 'conv' and spec.stride == 2 and spec.sd == 2
+                and spec.kd == 3 and spec.kh == 3 and spec.kw == 3 and spec.dil == 1 and spec.pad_t == 1 and spec.pad_l == 1
+                and spec.pad_d == 1 and spec.D == 2 * spec.Do and H == 2 * spec.Ho and W == 2 * spec.Wo and not _lib.DIAG_NO_PHASE_DGRAD):
+            gpost, ldgp = alloc_nhwc(Bimg, Cin, H, W, xv.dtype, xv.device)
+            packs, _keep = _phase_packs(weight, xv.dtype)       # (Cout, Cin, 3,3,3) IS the transposed convolution's (in, out, ...) layout
+            for (pd, ph, pw), wpk in zip(_PHASES, packs):
+                call("sdhip_conv2d_fwd_phase", ptr(g), ptr(wpk), ptr(gpost), None, 0, 1, B, spec.Ho, spec.Wo, Cout, ldg, Cin, ldgp,
+                     1 + ph, 1 + pw, spec.Do, 1 + pd, 1, pd, ph, pw, dt, stream_ptr())
+            if need_w:
+                gw, gb = wgrad(xv, ldx, g, ldg, weight, bias, spec, in_scale, in_shift, in_relu, groups)
+            return gpost, gw, gb
         if fused_bn:
             pass
         elif acc_into is not None:
@@ -1538,16 +1556,60 @@ _PHASE_INDEX = [a * 9 + b * 3 + c for (pd, ph, pw) in _PHASES for a in _PHASE_TA
 _phase_index_dev = {}
 
 
+def _phase_rows(weight, dt):
+    """Single-tap pack rows (src element offset, dst element offset, M, K, 1, stride_m, stride_k, 0) that build the eight packed
+    sub-kernels of a (Cin, Cout, 3, 3, 3) transposed-convolution weight straight from the parameter, one buffer behind the
+    other, and [(element offset, elements)] of the eight sub-kernels.  Needs one channel chunk (Cin <= 64 bf16 / 32 f32): a
+    tap's [Mpad][CK] block is then contiguous in the packed [kd][q][t][m][c] layout."""
+    Cin, Cout = weight.shape[0], weight.shape[1]
+    rows, spans, base = [], [], 0
+    for (pd, ph, pw) in _PHASES:
+        nd, T = 1 + pd, (1 + ph) * (1 + pw)
+        per = _lib.packed_elems(Cout, Cin, T, dt)
+        blk = per // T                                   # one tap's [Mpad][CK] block (single channel chunk)
+        for kdi, a in enumerate(_PHASE_TAPS[pd]):
+            t = 0
+            for b_ in _PHASE_TAPS[ph]:
+                for c_ in _PHASE_TAPS[pw]:
+                    rows.append((a * 9 + b_ * 3 + c_, base + kdi * per + t * blk, Cout, Cin, 1, 27, Cout * 27, 0))
+                    t += 1
+        spans.append((base, per * nd))
+        base += per * nd
+    return rows, spans
+
+
 def _phase_packs(weight, dtype):
-    """The eight packed sub-kernels of a (Cin, Cout, 3, 3, 3) ConvTranspose3d weight: one gather reorders the 27 taps phase by
-    phase into a (Cout, Cin, 27) buffer, from which every (phase, depth tap) is packed with its own strides."""
+    """The eight packed sub-kernels of a (Cin, Cout, 3, 3, 3) ConvTranspose3d weight (equally: of a stride-2 Conv3d weight
+    (Cout', Cin', 3, 3, 3) read as its adjoint), taps ordered phase by phase, input offset major.  One channel chunk: cached
+    per parameter like ops.packed_weight and, inside a training step, packed by the step's ONE batched launch (27 single-tap
+    rows per weight in the descriptor table).  Wider weights: a gather reorders the taps into a (Cout, Cin, 27) buffer, from
+    which every (phase, depth tap) is packed with its own strides."""
     Cin, Cout = weight.shape[0], weight.shape[1]
     dev = weight.device
+    dt = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+    if Cin <= (64 if dtype == torch.bfloat16 else 32) and weight.is_contiguous():
+        ent = _cache_entry(weight)
+        key = ('phase', 'fwd', dtype)
+        hit = ent.get(key)
+        c = _ctx[0]
+        rows, spans = _phase_rows(weight, dt)
+        ver = (weight._version, _pack_generation[0])
+        fresh = hit is not None and ((c is not None and c.frozen_pack) or (hit[0] == ver and not torch.cuda.is_current_stream_capturing()))
+        if fresh:
+            buf = hit[1]
+        else:
+            buf = torch.empty(spans[-1][0] + spans[-1][1], dtype=dtype, device=dev)
+            es = buf.element_size()
+            w = weight.detach()
+            for src_off, dst_off, M, K, T, sm, sk, flip in rows:
+                call("sdhip_conv_pack_weights", ctypes_ptr(w.data_ptr() + 4 * src_off), ctypes_ptr(buf.data_ptr() + es * dst_off),
+                     M, K, T, sm, sk, flip, dt, stream_ptr())
+            ent[key] = (ver, buf)
+        return [buf[o:o + n] for o, n in spans], buf
     idx = _phase_index_dev.get(str(dev))
     if idx is None:
         idx = _phase_index_dev[str(dev)] = torch.tensor(_PHASE_INDEX, dtype=torch.int64, device=dev)
     wre = weight.detach().reshape(Cin, Cout, 27).index_select(2, idx).transpose(0, 1).contiguous()      # (Cout, Cin, 27)
-    dt = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
     packs, off = [], 0
     for (pd, ph, pw) in _PHASES:
         nd, T = 1 + pd, (1 + ph) * (1 + pw)

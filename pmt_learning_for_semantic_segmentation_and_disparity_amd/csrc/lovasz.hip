@@ -23,6 +23,7 @@
 //          lanes below) and adds the column's running offset.  No barrier inside the round loop, nothing shared between waves:
 //          the result is the same on every run.
 #include "sdhip_common.h"
+#include "rows_lds.h"
 
 namespace {
 
@@ -172,32 +173,31 @@ __global__ __launch_bounds__(256) void lovasz_fgcount_kernel(const uint2* __rest
 }
 
 // kv[c][i] = (sort key of |fg - p_c| (see above), i | fg << 31), counts[c] += fg
-template <typename T>
+// ROWS: the workgroup's 256 pixel rows of logits and targets travel through LDS (rows_lds.h; many classes)
+template <typename T, bool ROWS>
 __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ t, int ldt,
                                                             uint2* __restrict__ kv,
-                                                            unsigned int* __restrict__ counts, long npix, int C, int ignore_void) {
+                                                            unsigned int* __restrict__ counts, long npix, int C, int ignore_void, int off_t) {
   // per-class pixel counts: LDS histogram per workgroup, one global atomic per class per workgroup (a global atomic per
   // pixel on C addresses serialises: ~10 ms for 1M pixels)
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
   __shared__ unsigned int hist[64];
   __shared__ unsigned int nvoid;
   if (threadIdx.x < 64) hist[threadIdx.x] = 0u;
   if (threadIdx.x == 0) nvoid = 0u;
   __syncthreads();
-  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
-    const T* yp = y + p * ldy;
+  auto pixel = [&](long p, const T* yp, const float* tp) {
     float mx = -INFINITY, tbest = -INFINITY;
     int label = 0;
     for (int c = 0; c < C; ++c) {
       mx = fmaxf(mx, Elem<T>::ld(yp + c));
-      const float tv = t[p * ldt + c];
+      const float tv = tp[c];
       if (tv > tbest) { tbest = tv; label = c; }   // argmax, first maximum wins (torch.argmax)
     }
     if (ignore_void && !(tbest > 0.f)) {   // void pixel
-      for (int c = 0; c < C; ++c) {
-        kv[(long)c * npix + p] = make_uint2(kKeyVoid, (unsigned int)p);
-      }
+      for (int c = 0; c < C; ++c) kv[(long)c * npix + p] = make_uint2(kKeyVoid, (unsigned int)p);
       atomicAdd(&nvoid, 1u);
-      continue;
+      return;
     }
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += __expf(Elem<T>::ld(yp + c) - mx);
@@ -208,6 +208,22 @@ __global__ __launch_bounds__(256) void lovasz_errors_kernel(const T* __restrict_
       kv[(long)c * npix + p] = make_uint2(kKeyOne - __float_as_uint(fminf(fabsf((float)fg - pc), 1.f)), (unsigned int)p | (fg << 31));
     }
     if (C <= 64) atomicAdd(hist + label, 1u); else atomicAdd(counts + label, 1u);
+  };
+  if constexpr (ROWS) {
+    T* const ly = reinterpret_cast<T*>(rsm);
+    float* const lt = reinterpret_cast<float*>(rsm + off_t);
+    const long ntiles = (npix + 255) / 256;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const long p0 = tile * 256;
+      const int n = (int)min(256L, npix - p0);
+      rows_to_lds(y + p0 * ldy, ly, n * ldy * (int)sizeof(T), threadIdx.x);
+      rows_to_lds(t + p0 * ldt, lt, n * ldt * 4, threadIdx.x);
+      __syncthreads();
+      if ((int)threadIdx.x < n) pixel(p0 + threadIdx.x, ly + threadIdx.x * ldy, lt + threadIdx.x * ldt);
+      __syncthreads();
+    }
+  } else {
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) pixel(p, y + p * ldy, t + p * ldt);
   }
   __syncthreads();
   if (C <= 64 && threadIdx.x < C && hist[threadIdx.x]) atomicAdd(counts + threadIdx.x, hist[threadIdx.x]);
@@ -275,11 +291,13 @@ __global__ __launch_bounds__(256) void lovasz_grad_kernel(const uint2* __restric
 
 // gy[p,k] += w/n_present * p_k * (g_k - sum_c g_c p_c), g_c = -sign(fg_c - p_c) * gerr[c][p]  (present classes only)
 // CM > 0: C <= CM, the pixel's probabilities and gradient factors stay in registers (one exp per class instead of three)
-template <typename T, int CM>
+template <typename T, int CM, bool ROWS = false>
 __global__ __launch_bounds__(256) void lovasz_backward_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ t, int ldt,
                                                               const float* __restrict__ gerr, const unsigned int* __restrict__ counts,
                                                               const double* __restrict__ lossc, T* __restrict__ gy, int ldg,
-                                                              double* __restrict__ loss, long npix, int C, float weight, int ignore_void) {
+                                                              double* __restrict__ loss, long npix, int C, float weight, int ignore_void,
+                                                              int off_t = 0, int off_g = 0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
   int npres = 0;
   unsigned long long present = 0ull;                  // (CM <= 64)
   for (int c = 0; c < C; ++c)
@@ -291,6 +309,62 @@ __global__ __launch_bounds__(256) void lovasz_backward_kernel(const T* __restric
     atomicAdd(loss, tot * (double)w);
   }
   if (!gy) return;
+  if constexpr (ROWS) {
+    // the workgroup's 256 pixel rows of logits, targets and the gradient (read, added to, written back) through LDS (rows_lds.h)
+    static_assert(CM > 0, "rows path keeps the pixel in registers");
+    T* const ly = reinterpret_cast<T*>(rsm);
+    float* const lt = reinterpret_cast<float*>(rsm + off_t);
+    T* const lg = reinterpret_cast<T*>(rsm + off_g);
+    const long ntiles = (npix + 255) / 256;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const long p0 = tile * 256;
+      const int n = (int)min(256L, npix - p0);
+      rows_to_lds(y + p0 * ldy, ly, n * ldy * (int)sizeof(T), threadIdx.x);
+      rows_to_lds(t + p0 * ldt, lt, n * ldt * 4, threadIdx.x);
+      rows_to_lds(gy + p0 * ldg, lg, n * ldg * (int)sizeof(T), threadIdx.x);
+      __syncthreads();
+      if ((int)threadIdx.x < n) {
+        const long p = p0 + threadIdx.x;
+        const T* yp = ly + threadIdx.x * ldy;
+        const float* tp = lt + threadIdx.x * ldt;
+        float pc[CM], g[CM];
+        float mx = -INFINITY, tbest = -INFINITY;
+        int label = 0;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+          pc[c] = c < C ? Elem<T>::ld(yp + c) : -INFINITY;
+          mx = fmaxf(mx, pc[c]);
+          const float tv = c < C ? tp[c] : -INFINITY;
+          if (tv > tbest) { tbest = tv; label = c; }
+        }
+        if (!(ignore_void && !(tbest > 0.f))) {        // (void pixel: not part of the loss)
+          float se = 0.f;
+#pragma unroll
+          for (int c = 0; c < CM; ++c) { pc[c] = c < C ? __expf(pc[c] - mx) : 0.f; se += pc[c]; }
+          const float inv = 1.f / se;
+          float dot = 0.f;
+#pragma unroll
+          for (int c = 0; c < CM; ++c) {
+            pc[c] *= inv;
+            g[c] = 0.f;
+            if (c < C && ((present >> c) & 1ull)) {
+              const float diff = (label == c ? 1.f : 0.f) - pc[c];
+              g[c] = (diff > 0.f ? -1.f : (diff < 0.f ? 1.f : 0.f)) * gerr[(long)c * npix + p];
+              dot = fmaf(g[c], pc[c], dot);
+            }
+          }
+          T* gp = lg + threadIdx.x * ldg;
+#pragma unroll
+          for (int k = 0; k < CM; ++k)
+            if (k < C) Elem<T>::st(gp + k, Elem<T>::ld(gp + k) + w * pc[k] * (g[k] - dot));
+        }
+      }
+      __syncthreads();
+      rows_from_lds(gy + p0 * ldg, lg, n * ldg * (int)sizeof(T), threadIdx.x);
+      __syncthreads();
+    }
+    return;
+  }
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
     const T* yp = y + p * ldy;
     if constexpr (CM > 0) {
@@ -364,9 +438,30 @@ __global__ __launch_bounds__(256) void lovasz_backward_kernel(const T* __restric
 template <typename T>
 void launch_lovasz_backward(dim3 grid, hipStream_t s, const T* y, int ldy, const float* t, int ldt, const float* gerr, const unsigned int* counts,
                             const double* lossc, T* gy, int ldg, double* loss, long npix, int C, float weight, int ignore_void) {
-  if (C <= 4) hipLaunchKernelGGL((lovasz_backward_kernel<T, 4>), grid, dim3(256), 0, s, y, ldy, t, ldt, gerr, counts, lossc, gy, ldg, loss, npix, C, weight, ignore_void);
-  else if (C <= 32) hipLaunchKernelGGL((lovasz_backward_kernel<T, 32>), grid, dim3(256), 0, s, y, ldy, t, ldt, gerr, counts, lossc, gy, ldg, loss, npix, C, weight, ignore_void);
-  else hipLaunchKernelGGL((lovasz_backward_kernel<T, 0>), grid, dim3(256), 0, s, y, ldy, t, ldt, gerr, counts, lossc, gy, ldg, loss, npix, C, weight, ignore_void);
+  const size_t by = rows_lds_bytes(ldy, sizeof(T)), bt = rows_lds_bytes(ldt, 4), bg = rows_lds_bytes(ldg, sizeof(T));
+  if (C > 4 && C <= 32 && gy && by + bt + bg <= 60 * 1024 && ((uintptr_t)y & 3) == 0 && ((uintptr_t)gy & 3) == 0) {
+    long b = (npix + 255) / 256;
+    if (b > 768) b = 768;
+    hipLaunchKernelGGL((lovasz_backward_kernel<T, 32, true>), dim3((unsigned)b), dim3(256), by + bt + bg, s, y, ldy, t, ldt, gerr, counts, lossc, gy, ldg, loss,
+                       npix, C, weight, ignore_void, (int)by, (int)(by + bt));
+    return;
+  }
+  if (C <= 4) hipLaunchKernelGGL((lovasz_backward_kernel<T, 4>), grid, dim3(256), 0, s, y, ldy, t, ldt, gerr, counts, lossc, gy, ldg, loss, npix, C, weight, ignore_void, 0, 0);
+  else if (C <= 32) hipLaunchKernelGGL((lovasz_backward_kernel<T, 32>), grid, dim3(256), 0, s, y, ldy, t, ldt, gerr, counts, lossc, gy, ldg, loss, npix, C, weight, ignore_void, 0, 0);
+  else hipLaunchKernelGGL((lovasz_backward_kernel<T, 0>), grid, dim3(256), 0, s, y, ldy, t, ldt, gerr, counts, lossc, gy, ldg, loss, npix, C, weight, ignore_void, 0, 0);
+}
+
+template <typename T>
+void launch_lovasz_errors(hipStream_t s, const T* y, int ldy, const float* t, int ldt, uint2* kv, unsigned int* counts, long npix, int C, int ignore_void) {
+  const size_t by = rows_lds_bytes(ldy, sizeof(T)), bt = rows_lds_bytes(ldt, 4);
+  long b = (npix + 255) / 256;
+  if (C > 4 && by + bt <= 60 * 1024 && ((uintptr_t)y & 3) == 0) {
+    if (b > 768) b = 768;
+    hipLaunchKernelGGL((lovasz_errors_kernel<T, true>), dim3((unsigned)b), dim3(256), by + bt, s, y, ldy, t, ldt, kv, counts, npix, C, ignore_void, (int)by);
+    return;
+  }
+  if (b > 512) b = 512;     // (closing atomics per workgroup: see grid_for)
+  hipLaunchKernelGGL((lovasz_errors_kernel<T, false>), dim3((unsigned)b), dim3(256), 0, s, y, ldy, t, ldt, kv, counts, npix, C, ignore_void, 0);
 }
 
 struct Layout {
@@ -437,10 +532,8 @@ extern "C" int sdhip_lovasz_softmax(const void* logits, int ldy, const float* ta
   SDHIP_CHECK_ARG(C <= 65535, "lovasz_softmax: more than 65535 classes");
   // (a kernel, not hipMemsetAsync: the step is replayed from a hipGraph, and everything in it is kept to kernel nodes)
   if (sdhip_zero_async(ws + L.counts, L.bfg - L.counts, s) != hipSuccess) SDHIP_FAIL(SDHIP_ERR_LAUNCH, "lovasz_softmax: clearing the counters failed");
-  if (dtype == SDHIP_F32)
-    hipLaunchKernelGGL(lovasz_errors_kernel<float>, grid_for(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, kv_a, counts, npix, C, ignore_void);
-  else
-    hipLaunchKernelGGL(lovasz_errors_kernel<bf16_t>, grid_for(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, kv_a, counts, npix, C, ignore_void);
+  if (dtype == SDHIP_F32) launch_lovasz_errors<float>(s, (const float*)logits, ldy, target, ldt, kv_a, counts, npix, C, ignore_void);
+  else launch_lovasz_errors<bf16_t>(s, (const bf16_t*)logits, ldy, target, ldt, kv_a, counts, npix, C, ignore_void);
   // four stable passes over bits 0-7, 8-15, 16-23, 24-31 (keys < 2^30); a -> b -> a -> b -> a: the sorted arrays end in `a`
   const dim3 gs((unsigned)((L.cols + 3) / 4), (unsigned)C);
   for (int pass = 0; pass < 4; ++pass) {

@@ -5,6 +5,7 @@
 // categoricalCrossEntropy (util/utilTorchLoss.py:373-378, fed by F.log_softmax at
 // losses/multiLosses.py:42) and nn.L1Loss (losses/multiLosses.py:141).
 #include "sdhip_common.h"
+#include "rows_lds.h"
 
 namespace {
 
@@ -78,6 +79,48 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ y, int ld
   if (threadIdx.x == 0) atomicAdd(loss, (double)tot * (double)wnorm);
 }
 
+// The same for many classes (5 <= C <= 64; 19 Cityscapes classes): the workgroup's 256 pixel rows travel through LDS (rows_lds.h)
+template <typename T>
+__global__ __launch_bounds__(256) void ce_rows_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ t, int ldt,
+                                                      T* __restrict__ gy, int ldg, double* __restrict__ loss, long npix, int C, float wnorm,
+                                                      int off_t, int off_g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+  __shared__ float sh[4];
+  T* const ly = reinterpret_cast<T*>(rsm);
+  float* const lt = reinterpret_cast<float*>(rsm + off_t);
+  T* const lg = reinterpret_cast<T*>(rsm + off_g);
+  const int tid = threadIdx.x;
+  const long ntiles = (npix + 255) / 256;
+  float part = 0.f;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long p0 = tile * 256;
+    const int n = (int)min(256L, npix - p0);
+    rows_to_lds(y + p0 * ldy, ly, n * ldy * (int)sizeof(T), tid);
+    rows_to_lds(t + p0 * ldt, lt, n * ldt * 4, tid);
+    __syncthreads();
+    if (tid < n) {
+      const T* yp = ly + tid * ldy;
+      const float* tp = lt + tid * ldt;
+      float mx = -INFINITY;
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, Elem<T>::ld(yp + c));
+      float se = 0.f, ts = 0.f, dot = 0.f;
+      for (int c = 0; c < C; ++c) { const float z = Elem<T>::ld(yp + c) - mx; se += __expf(z); ts += tp[c]; dot += tp[c] * z; }
+      part += ts * __logf(se) - dot;
+      if (gy) {
+        const float inv = 1.f / se;
+        T* gp = lg + tid * ldg;
+        for (int c = 0; c < C; ++c) Elem<T>::st(gp + c, wnorm * (__expf(Elem<T>::ld(yp + c) - mx) * inv * ts - tp[c]));
+        for (int c = C; c < ldg; ++c) Elem<T>::st(gp + c, 0.f);      // (pad channels of the pixel stride: defined, never data)
+      }
+    }
+    __syncthreads();
+    if (gy) rows_from_lds(gy + p0 * ldg, lg, n * ldg * (int)sizeof(T), tid);
+    __syncthreads();
+  }
+  const float tot = block_sum(part, sh);
+  if (threadIdx.x == 0) atomicAdd(loss, (double)tot * (double)wnorm);
+}
+
 // loss += weight/n * sum |a - b| ; ga = weight/n * sign(a - b).  mask_nonpositive: elements whose target is <= 0 count as
 // zero difference but stay in the mean (L1(pred*zeros, disp*zeros), zeros = disp > 0: losses/multiLosses.py:138-141)
 template <typename T>
@@ -131,10 +174,23 @@ extern "C" int sdhip_ce_loss(const void* logits, int ldy, const float* target, i
   SDHIP_CHECK_ARG(logits && target && loss && npix > 0 && C > 0 && ldy >= C && ldt >= C && (!grad || ldg >= C), "ce_loss: bad arguments");
   SDHIP_CHECK_ARG(dtype == SDHIP_F32 || dtype == SDHIP_BF16, "ce_loss: unknown dtype %d", dtype);
   const float wn = weight / (float)npix;
+  hipStream_t s = (hipStream_t)stream;
+  const int es = dtype == SDHIP_F32 ? 4 : 2;
+  const size_t by = rows_lds_bytes(ldy, es), bt = rows_lds_bytes(ldt, 4), bg = grad ? rows_lds_bytes(ldg, es) : 0;
+  if (C > 4 && C <= 64 && by + bt + bg <= 60 * 1024 && ((uintptr_t)logits & 3) == 0 && (!grad || ((uintptr_t)grad & 3) == 0)) {
+    long b = (npix + 255) / 256;
+    if (b > 768) b = 768;
+    if (dtype == SDHIP_F32)
+      hipLaunchKernelGGL(ce_rows_kernel<float>, dim3((unsigned)b), dim3(256), by + bt + bg, s, (const float*)logits, ldy, target, ldt, (float*)grad, ldg, loss, npix, C, wn, (int)by, (int)(by + bt));
+    else
+      hipLaunchKernelGGL(ce_rows_kernel<bf16_t>, dim3((unsigned)b), dim3(256), by + bt + bg, s, (const bf16_t*)logits, ldy, target, ldt, (bf16_t*)grad, ldg, loss, npix, C, wn, (int)by, (int)(by + bt));
+    SDHIP_LAUNCH_CHECK();
+    return SDHIP_OK;
+  }
   if (dtype == SDHIP_F32)
-    hipLaunchKernelGGL(ce_kernel<float>, grid_loss(npix), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ldy, target, ldt, (float*)grad, ldg, loss, npix, C, wn);
+    hipLaunchKernelGGL(ce_kernel<float>, grid_loss(npix), dim3(256), 0, s, (const float*)logits, ldy, target, ldt, (float*)grad, ldg, loss, npix, C, wn);
   else
-    hipLaunchKernelGGL(ce_kernel<bf16_t>, grid_loss(npix), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ldy, target, ldt, (bf16_t*)grad, ldg, loss, npix, C, wn);
+    hipLaunchKernelGGL(ce_kernel<bf16_t>, grid_loss(npix), dim3(256), 0, s, (const bf16_t*)logits, ldy, target, ldt, (bf16_t*)grad, ldg, loss, npix, C, wn);
   SDHIP_LAUNCH_CHECK();
   return SDHIP_OK;
 }

@@ -42,3 +42,20 @@ def test_product_has_no_cpu_path():
     from pmt_learning_for_semantic_segmentation_and_disparity_amd import nn as N, SdhipError
     with pytest.raises(SdhipError):
         N.SpatialCorrelationSampler(1, (1, 17))(torch.zeros(1, 8, 4, 4), torch.zeros(1, 8, 4, 4))
+
+
+def test_phase_pack_rows_tile_the_eight_sub_kernels():
+    """Host logic of the sub-pixel phases of a 3x3x3 stride-2 (transposed) convolution (ops._phase_rows: the descriptor rows the
+    step's batched pack launch replays): the 27 single-tap rows read every tap of the parameter exactly once, in the order of
+    ops._PHASE_INDEX, and their destinations tile the eight packed sub-kernels [depth tap][tap][Mpad][64] without gaps."""
+    import torch
+    from pmt_learning_for_semantic_segmentation_and_disparity_amd import ops, _lib
+    w = torch.zeros(64, 32, 3, 3, 3)                       # ConvTranspose3d(64, 32) / the adjoint view of Conv3d(32 -> 64, stride 2)
+    rows, spans = ops._phase_rows(w, _lib.BF16)
+    assert [r[0] for r in rows] == ops._PHASE_INDEX and sorted(r[0] for r in rows) == list(range(27))
+    blk = _lib.packed_elems(32, 64, 1, _lib.BF16)          # one tap: [Mpad = 32][64]
+    assert blk == 32 * 64
+    assert sorted(r[1] for r in rows) == [i * blk for i in range(27)]
+    assert all(r[2:] == (32, 64, 1, 27, 32 * 27, 0) for r in rows)
+    assert [n for _, n in spans] == [blk * (1 + pd) * (1 + ph) * (1 + pw) for (pd, ph, pw) in ops._PHASES]
+    assert spans[0][0] == 0 and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(7))

@@ -363,7 +363,7 @@ struct FaninArgs {
 
 constexpr int kFaninMaxNT = 7;           // 16-pixel halo blocks per wave: halo <= 448 pixels
 
-template <int KD, int NK>
+template <int KD, int NK, int KHW = 0>            // KHW = 3: kh = kw = 3 known at compile time (the tap sum unrolls to constant LDS offsets)
 __global__ __launch_bounds__(256) void conv_fanin_kernel(const FaninArgs p) {
   constexpr int TH = 8, TW = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char fan_smem[];
@@ -450,8 +450,13 @@ __global__ __launch_bounds__(256) void conv_fanin_kernel(const FaninArgs p) {
     for (int k = 0; k < KD; ++k) {
       float a = 0.f;
       const float* Pk = P + (k * T2) * p.pitch + r * IW + c;
-      for (int khi = 0; khi < p.kh; ++khi)
-        for (int kwi = 0; kwi < p.kw; ++kwi) a += Pk[(khi * p.kw + kwi) * p.pitch + khi * IW + kwi];
+      if constexpr (KHW == 3) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a += Pk[t * p.pitch + (t / 3) * (TW + 2) + t % 3];
+      } else {
+        for (int khi = 0; khi < p.kh; ++khi)
+          for (int kwi = 0; kwi < p.kw; ++kwi) a += Pk[(khi * p.kw + kwi) * p.pitch + khi * IW + kwi];
+      }
       S[k] = a;
     }
     if constexpr (KD == 1) {
@@ -484,7 +489,8 @@ inline int launch_fanin(FaninArgs a, int kd, hipStream_t s) {
   a.dpw = dpw; a.zsegs = sdhip_cdiv(a.Do, dpw);
   if ((long)a.B * a.zsegs > 65535) return 1;
   dim3 grid(sdhip_cdiv(a.Ho, 8) * sdhip_cdiv(a.Wo, 32), a.B * a.zsegs);
-  if (kd == 3) hipLaunchKernelGGL((conv_fanin_kernel<3, 1>), grid, dim3(256), lds, s, a);
+  if (kd == 3 && a.kh == 3 && a.kw == 3) hipLaunchKernelGGL((conv_fanin_kernel<3, 1, 3>), grid, dim3(256), lds, s, a);
+  else if (kd == 3) hipLaunchKernelGGL((conv_fanin_kernel<3, 1>), grid, dim3(256), lds, s, a);
   else if (a.Cin <= 32) hipLaunchKernelGGL((conv_fanin_kernel<1, 1>), grid, dim3(256), lds, s, a);
   else hipLaunchKernelGGL((conv_fanin_kernel<1, 2>), grid, dim3(256), lds, s, a);
   SDHIP_LAUNCH_CHECK();

@@ -279,7 +279,7 @@ def test_fanin_conv_one_output_map(k, B, ci, H, W, act):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,ci,co", [(5, 64, 64), (5, 32, 32), (3, 32, 64)])
+@pytest.mark.parametrize("k,ci,co", [(5, 64, 64), (5, 32, 32), (3, 32, 64), (3, 32, 32), (3, 16, 24)])
 def test_band_full_size_translation_equivariance(k, ci, co):
     """Size-independent property at the benchmark's full size (8 x 256 x 512): shifting the input by one tile (16 rows, 32
     columns) shifts the output by the same amount, bit for bit, wherever the receptive field stays inside the image — every

@@ -244,6 +244,11 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
   int wsel = 0;
   bool epi_counted = false;                                // the previous chunk ended with exactly NSTORE stores per lane
 
+  // 3x3, <= 32 output channels: the resident weights (9 taps x 2 fragments) stay in REGISTERS — every tile uses the same ones, and with
+  // two output-channel tiles per wave the weight fragments were a third of the kernel's LDS reads, which bound it (6 reads per 8 MFMAs)
+  constexpr bool WREG = C::WRES && BN <= 32;
+  u32x4 wreg[WREG ? C::TPS : 1][NT_CO];
+
   for (int c = 0; c < nchunks; ++c) {
     const int hsel = c & 1;
     const bool has_next = c + 1 < nchunks;
@@ -276,6 +281,14 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
 
       const unsigned char* const wl = smem + 2 * HB + wsel * WB + a_base;
       const unsigned char* const hj = hb + j * C::RS * (IWp * 64);
+      if constexpr (WREG) {
+        if (c == 0) {                                       // (the weights landed with the first image: the wait above)
+#pragma unroll
+          for (int t = 0; t < C::TPS; ++t)
+#pragma unroll
+            for (int mi = 0; mi < NT_CO; ++mi) wreg[t][mi] = *reinterpret_cast<const u32x4*>(wl + t * (BN * 64) + mi * 1024);
+        }
+      }
       u32x4 af[2][NT_CO], bf[2][NT_PIX];
       if constexpr (DBG) if (dbg & 32) {
 #pragma unroll
@@ -286,7 +299,10 @@ __global__ __launch_bounds__(NW * 64) void conv_band_kernel(const BandArgs p) {
       auto load = [&](int set, int t) {                     // tap t of the stage: kernel row t / K of it, column t % K
         if (dbg & 32) return;
 #pragma unroll
-        for (int mi = 0; mi < NT_CO; ++mi) af[set][mi] = *reinterpret_cast<const u32x4*>(wl + t * (BN * 64) + mi * 1024);
+        for (int mi = 0; mi < NT_CO; ++mi) {
+          if constexpr (WREG) af[set][mi] = wreg[t][mi];
+          else af[set][mi] = *reinterpret_cast<const u32x4*>(wl + t * (BN * 64) + mi * 1024);
+        }
 #pragma unroll
         for (int ni = 0; ni < NT_PIX; ++ni)
           bf[set][ni] = *reinterpret_cast<const u32x4*>(hj + b_k[t % K] + ((t / K + (ni >> 1)) * IWp + (ni & 1) * 16) * 64);
